@@ -1,0 +1,189 @@
+/*
+ * mi355_decode.h -- C ABI of libmi355_decode.so: the batched-decode hot path
+ * (paged-attention prefill/decode over a block-table KV cache, RMSNorm, RoPE +
+ * KV-cache write, SwiGLU gate, sampling) as hand-written HIP for gfx950.
+ *
+ * What this boundary replaces.  The reference harness never calls these
+ * operators itself: it starts an engine container and talks HTTP to it.  The
+ * engine it starts is the third-party image vllm/vllm-openai:v0.9.1
+ * (benchmark-vllm/vllm_manager.py:371-375; local variant vllm-cpu-env:latest,
+ * benchmark-vllm/vllm_templates.py:124), configured only through CLI flags
+ * (benchmark-vllm/vllm_templates.py:50-87, vllm_manager.py:399-416).  Each entry
+ * point below stands in for the operator of that engine's model step named in
+ * its comment, and cites the reference flag that parameterises it.  The Python
+ * host (vllm-backend-public_amd/mi355_decode) binds this file with ctypes.
+ *
+ * Conventions
+ *  - plain C: raw device pointers, explicit sizes/strides (in ELEMENTS), no
+ *    framework types.  The caller owns every buffer; nothing is allocated here.
+ *  - `stream` is a hipStream_t passed as void*; every call only enqueues work on
+ *    it (no synchronisation, safe under HIP graph capture).
+ *  - return value: MI355_OK or a negative MI355_ERR_*; the reason is kept per
+ *    thread and returned by mi355_last_error().  Arguments are validated on the
+ *    host before any launch; a rejected call launches nothing.
+ *  - 16-bit tensors are bf16 or fp16 as selected by `dtype`; all pointers to
+ *    them must be 16-byte aligned and row strides multiples of 8 elements.
+ *  - one process drives one GPU (tensor parallel = one process per GPU); calls
+ *    are re-entrant across streams.
+ *
+ * Paged KV cache layout, per layer (block_size is fixed at 16 tokens):
+ *    K cache  [num_blocks][kv_heads][16][head_dim]     token rows
+ *    V cache  [num_blocks][kv_heads][head_dim][16]     token columns (transposed
+ *             so a PV MFMA operand is one 16-byte load)
+ *    slot = block_id * 16 + offset.
+ */
+#ifndef MI355_DECODE_H
+#define MI355_DECODE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_ABI_VERSION 1
+#define MI355_BLOCK_SIZE 16
+
+enum mi355_dtype { MI355_BF16 = 0, MI355_F16 = 1, MI355_F32 = 2 };
+
+enum mi355_status {
+  MI355_OK = 0,
+  MI355_ERR_INVALID = -1,     /* bad argument (null, misaligned, size) */
+  MI355_ERR_UNSUPPORTED = -2, /* shape/dtype outside what the kernels cover */
+  MI355_ERR_LAUNCH = -3       /* HIP reported an error at launch */
+};
+
+/* ABI version of the loaded library (== MI355_ABI_VERSION at build time). */
+int32_t mi355_abi_version(void);
+
+/* Message for the last non-OK status returned on the calling thread. */
+const char* mi355_last_error(void);
+
+/* Name of the GPU architecture the kernels were compiled for ("gfx950"). */
+const char* mi355_target_arch(void);
+
+/*
+ * RMSNorm:  out = round(round(x * rsqrt(mean(x^2) + eps)) * weight), fp32
+ * reduction.  x, out [num_tokens, hidden] with the given row strides; weight
+ * [hidden].  Replaces the engine's rms_norm (input_layernorm / final norm of the
+ * model selected by --model, vllm_templates.py:51; arithmetic type from --dtype,
+ * vllm_templates.py:57).
+ */
+int32_t mi355_rms_norm(void* out, const void* x, const void* weight,
+                       int64_t num_tokens, int32_t hidden,
+                       int64_t x_stride, int64_t out_stride,
+                       float eps, int32_t dtype, void* stream);
+
+/*
+ * Residual add fused with RMSNorm:  residual = round(x + residual);
+ * out = rms_norm(residual).  `out` may alias `x`.  Replaces the engine's
+ * fused_add_rms_norm (same flags as above).
+ */
+int32_t mi355_fused_add_rms_norm(void* out, const void* x, void* residual,
+                                 const void* weight, int64_t num_tokens,
+                                 int32_t hidden, int64_t x_stride,
+                                 int64_t out_stride, int64_t residual_stride,
+                                 float eps, int32_t dtype, void* stream);
+
+/*
+ * Rotary embedding (NeoX / rotate-half pairing (i, i + head_dim/2)) applied in
+ * place to the q and k parts of the packed QKV projection output, fused with the
+ * paged KV-cache store of k (rotated) and v.
+ *   qkv          [num_tokens, (num_heads + 2*num_kv_heads) * head_dim]
+ *   positions    int64 [num_tokens]   (clamped to max_position - 1)
+ *   cos_sin      [max_position, head_dim] in `dtype`: cos | sin halves
+ *   slot_mapping int64 [num_tokens]; slot < 0 or >= num_blocks*16: not stored
+ * Rounds at the points a 16-bit model does: each product and the sum.
+ * Replaces the engine's rotary_embedding + reshape_and_cache; the page size is
+ * the harness's --block-size (vllm_templates.py:54; benchmark-vllm/models.py:10).
+ */
+int32_t mi355_rope_kv_write(void* qkv, int64_t qkv_stride,
+                            const int64_t* positions, const void* cos_sin,
+                            int32_t max_position, const int64_t* slot_mapping,
+                            void* k_cache, void* v_cache, int32_t num_blocks,
+                            int64_t num_tokens, int32_t num_heads,
+                            int32_t num_kv_heads, int32_t head_dim,
+                            int32_t dtype, void* stream);
+
+/*
+ * Workspace (bytes) mi355_paged_attn_decode needs for a given split count.
+ * 0 when num_splits <= 1.
+ */
+int64_t mi355_paged_attn_decode_workspace(int32_t num_seqs, int32_t num_heads,
+                                          int32_t head_dim, int32_t num_splits);
+
+/*
+ * Decode attention, one new query token per sequence, keys/values read from the
+ * paged cache through the block table:
+ *   out[b, h, :] = softmax(q[b, h, :] . K_b^T * scale) V_b   over context_lens[b]
+ * tokens (the new token's k/v already stored).  fp32 softmax and accumulation,
+ * one rounding of the result.  Grouped-query: num_heads / num_kv_heads (<= 16)
+ * query heads share a kv head and its pages are read once for the group.
+ *   q            [num_seqs, num_heads, head_dim], token stride q_stride
+ *   out          [num_seqs, num_heads, head_dim] contiguous
+ *   block_tables int32 [num_seqs, max_blocks_per_seq]
+ *   context_lens int32 [num_seqs]  (0 -> zeros)
+ *   num_splits   >= 1: the context of a sequence is cut into this many ranges
+ *                handled by separate workgroups and merged by a second kernel;
+ *                needs `workspace` of mi355_paged_attn_decode_workspace() bytes.
+ * Replaces the engine's paged_attention_v1/v2 (batch = --max-num-seqs,
+ * vllm_templates.py:53; context bound = --max-model-len, vllm_templates.py:72-73).
+ */
+int32_t mi355_paged_attn_decode(void* out, const void* q, int64_t q_stride,
+                                const void* k_cache, const void* v_cache,
+                                int32_t num_blocks, const int32_t* block_tables,
+                                int32_t max_blocks_per_seq,
+                                const int32_t* context_lens, int32_t num_seqs,
+                                int32_t num_heads, int32_t num_kv_heads,
+                                int32_t head_dim, float scale,
+                                int32_t num_splits, void* workspace,
+                                int64_t workspace_bytes, int32_t dtype,
+                                void* stream);
+
+/*
+ * Prefill (and chunked-prefill) attention: causal attention of packed
+ * variable-length query chunks over keys/values already stored in the paged
+ * cache.  Sequence i owns query rows [cu_seqlens[i], cu_seqlens[i+1]) sitting at
+ * absolute positions [context_lens[i] - q_len_i, context_lens[i]); the row at
+ * position p attends keys [0, p].
+ *   q, out       [num_tokens, num_heads, head_dim], token strides q_stride /
+ *                out_stride
+ *   cu_seqlens   int32 [num_seqs + 1]
+ *   max_q_len    upper bound of q_len_i known to the host (sizes the grid)
+ * Replaces the engine's varlen flash-attention prefill.
+ */
+int32_t mi355_paged_attn_prefill(void* out, int64_t out_stride, const void* q,
+                                 int64_t q_stride, const void* k_cache,
+                                 const void* v_cache, int32_t num_blocks,
+                                 const int32_t* block_tables,
+                                 int32_t max_blocks_per_seq,
+                                 const int32_t* cu_seqlens,
+                                 const int32_t* context_lens, int32_t num_seqs,
+                                 int32_t max_q_len, int32_t num_heads,
+                                 int32_t num_kv_heads, int32_t head_dim,
+                                 float scale, int32_t dtype, void* stream);
+
+/*
+ * SwiGLU gate:  out[t, :] = round(round(silu(x[t, :F])) * x[t, F:2F]).
+ * x [num_tokens, 2F] (row stride x_stride), out [num_tokens, F] contiguous.
+ * Replaces the engine's silu_and_mul.
+ */
+int32_t mi355_silu_and_mul(void* out, const void* x, int64_t x_stride,
+                           int64_t num_tokens, int32_t inter, int32_t dtype,
+                           void* stream);
+
+/*
+ * Greedy sampling: out_ids[b] = argmax_v logits[b, v]; lowest index on ties, a
+ * NaN counts as the maximum (torch.argmax semantics).  logits may be bf16, fp16
+ * or fp32 (logits_dtype); row stride in elements.  Serves requests with
+ * temperature == 0 on POST /v1/completions
+ * (benchmark-deployer/docs/deployment/post_run.md:46).
+ */
+int32_t mi355_argmax(int64_t* out_ids, const void* logits,
+                     int64_t logits_stride, int32_t num_rows, int32_t vocab,
+                     int32_t logits_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_DECODE_H */

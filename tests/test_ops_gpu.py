@@ -1,0 +1,353 @@
+"""Parity of the HIP operators (called through the C ABI via mi355_decode.ops)
+against the numpy oracle on the same seeded inputs, and against the committed HF
+vectors.  GPU only.
+
+Bars (written next to each check):
+  * rotary embedding, KV-cache store, residual add, argmax: bit-exact.
+  * RMSNorm, SwiGLU gate: identical up to single-ulp flips of the 16-bit result
+    on a small fraction of elements (reduction order / expf rounding).
+  * attention: fp32 softmax/accumulation with probabilities rounded to the model
+    dtype before the PV product: |err| <= 8e-3 * max|ref| for bf16,
+    <= 1e-3 * max|ref| for fp16 (the north-star tolerance), plus one output ulp.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import ops_ref as R  # noqa: E402
+
+DT = {"bfloat16": torch.bfloat16, "float16": torch.float16}
+ULP = {"bfloat16": 2.0 ** -7, "float16": 2.0 ** -10}
+ATTN_TOL = {"bfloat16": 8e-3, "float16": 1e-3}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from mi355_decode import ops as _ops
+    return _ops
+
+
+def rng_for(*key):
+    import zlib
+    return np.random.Generator(np.random.PCG64(zlib.crc32(repr(key).encode())))
+
+
+def grid(rng, shape, dtype, scale=1.0):
+    return R.round_to((rng.standard_normal(shape) * scale).astype(np.float32), dtype)
+
+
+def dev(x, dtype):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DT[dtype]).cuda()
+
+
+def host(t):
+    return t.float().cpu().numpy()
+
+
+def assert_ulp_close(got, ref, dtype, max_frac):
+    diff = np.abs(got - ref)
+    tol = ULP[dtype] * np.maximum(np.abs(ref), 1e-30) * 1.01
+    assert (diff <= tol).all(), f"max diff {diff.max()} (worst ref {ref.flat[diff.argmax()]})"
+    frac = (diff > 0).mean()
+    assert frac <= max_frac, f"{frac:.5f} of elements differ by one ulp (> {max_frac})"
+
+
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("T,H", [(1, 256), (5, 448), (32, 4096), (3, 8192), (2, 16384), (130, 1024)])
+def test_rms_norm(ops, dtype, T, H):
+    rng = rng_for("rms", dtype, T, H)
+    x, w, res = grid(rng, (T, H), dtype, 2.0), R.round_to(1 + 0.1 * rng.standard_normal(H), dtype), grid(rng, (T, H), dtype)
+    eps = 1e-5
+    y = ops.rms_norm(dev(x, dtype), dev(w, dtype), eps)
+    assert_ulp_close(host(y), R.rms_norm(x, w, eps, dtype), dtype, 0.005)
+
+    xd, rd = dev(x, dtype), dev(res, dtype)
+    out = ops.fused_add_rms_norm(xd, rd, dev(w, dtype), eps)
+    y_ref, z_ref = R.fused_add_rms_norm(x, res, w, eps, dtype)
+    np.testing.assert_array_equal(host(rd), z_ref)            # residual add: bit-exact
+    assert out.data_ptr() == xd.data_ptr()                     # in place by default
+    assert_ulp_close(host(out), y_ref, dtype, 0.005)
+
+
+def test_rms_norm_strided_rows(ops):
+    """Row strides larger than the width (a column slice of a wider buffer)."""
+    dtype = "bfloat16"
+    rng = rng_for("rms-strided")
+    big = grid(rng, (7, 1024), dtype)
+    w = R.round_to(1 + 0.1 * rng.standard_normal(512), dtype)
+    bd = dev(big, dtype)
+    y = ops.rms_norm(bd[:, 256:768], dev(w, dtype), 1e-6)
+    assert_ulp_close(host(y), R.rms_norm(big[:, 256:768], w, 1e-6, dtype), dtype, 0.005)
+
+
+def test_rms_norm_golden(ops, ops_golden):
+    g = ops_golden
+    for tag in "abc":
+        x, w, eps = g[f"rms_{tag}_x"], g[f"rms_{tag}_w"], float(g[f"rms_{tag}_eps"])
+        y = ops.rms_norm(dev(x, "bfloat16"), dev(w, "bfloat16"), eps)
+        assert_ulp_close(host(y), g[f"rms_{tag}_y_bfloat16"], "bfloat16", 0.005)
+
+
+def test_rejects_bad_arguments(ops):
+    from mi355_decode._lib import Mi355Error
+    x = torch.zeros(4, 250, dtype=torch.bfloat16, device="cuda")      # hidden not a multiple of 8
+    with pytest.raises(Mi355Error, match="multiple of 8"):
+        ops.rms_norm(x, torch.ones(250, dtype=torch.bfloat16, device="cuda"), 1e-5)
+    with pytest.raises(TypeError):
+        ops.rms_norm(x.float(), torch.ones(250, device="cuda"), 1e-5)
+    with pytest.raises(ValueError):
+        ops.rms_norm(x.cpu(), torch.ones(250, dtype=torch.bfloat16), 1e-5)
+
+
+# --------------------------------------------------------------------------- #
+def make_cache(num_blocks, kvh, d, dtype, fill=None):
+    kc = torch.zeros(num_blocks, kvh, 16, d, dtype=DT[dtype], device="cuda")
+    vc = torch.zeros(num_blocks, kvh, d, 16, dtype=DT[dtype], device="cuda")
+    if fill is not None:
+        kc.fill_(fill), vc.fill_(fill)
+    return kc, vc
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("nh,kvh,d", [(4, 2, 64), (8, 2, 128), (32, 8, 128), (7, 1, 64)])
+def test_rope_kv_write(ops, dtype, nh, kvh, d):
+    rng = rng_for("rope", dtype, nh, kvh, d)
+    T, nblk, max_pos = 37, 12, 512
+    table = R.rope_cos_sin_table(max_pos, d, 5e5, dtype)
+    qkv = grid(rng, (T, (nh + 2 * kvh) * d), dtype)
+    pos = rng.integers(0, max_pos, T).astype(np.int64)
+    slots = rng.permutation(nblk * 16)[:T].astype(np.int64)
+    slots[3] = -1                                             # padding token: rotated, not stored
+    kc_ref = np.zeros((nblk, kvh, 16, d), np.float32)
+    vc_ref = np.zeros((nblk, kvh, d, 16), np.float32)
+    ref = R.rope_kv_write(qkv, pos, table, slots, kc_ref, vc_ref, nh, kvh, d, dtype)
+
+    kc, vc = make_cache(nblk, kvh, d, dtype)
+    qd = dev(qkv, dtype)
+    ops.rope_kv_write(qd, torch.from_numpy(pos).cuda(), dev(table, dtype), torch.from_numpy(slots).cuda(),
+                      kc, vc, nh, kvh, d)
+    np.testing.assert_array_equal(host(qd), ref)              # bit-exact
+    np.testing.assert_array_equal(host(kc), kc_ref)
+    np.testing.assert_array_equal(host(vc), vc_ref)
+
+
+def test_rope_golden(ops, ops_golden):
+    """HF apply_rotary_pos_emb outputs (bf16), using HF's own cos/sin rows as the table."""
+    g = ops_golden
+    for tag, d, nh, kvh in (("d64", 64, 4, 2), ("d128", 128, 8, 2), ("q128", 128, 7, 1)):
+        q, k = g[f"rope_{tag}_q"], g[f"rope_{tag}_k"]
+        T = q.shape[0]
+        tab = np.concatenate([g[f"rope_{tag}_cos_bfloat16"][:, : d // 2], g[f"rope_{tag}_sin_bfloat16"][:, : d // 2]], 1)
+        v = np.zeros_like(k)
+        qkv = np.concatenate([q.reshape(T, -1), k.reshape(T, -1), v.reshape(T, -1)], 1)
+        kc, vc = make_cache(2, kvh, d, "bfloat16")
+        qd = dev(qkv, "bfloat16")
+        ops.rope_kv_write(qd, torch.arange(T, device="cuda"), dev(tab, "bfloat16"),
+                          torch.arange(T, device="cuda"), kc, vc, nh, kvh, d)
+        out = host(qd)
+        np.testing.assert_array_equal(out[:, : nh * d].reshape(T, nh, d), g[f"rope_{tag}_qo_bfloat16"])
+        np.testing.assert_array_equal(out[:, nh * d:(nh + kvh) * d].reshape(T, kvh, d), g[f"rope_{tag}_ko_bfloat16"])
+        # and the rotated keys landed in the page
+        np.testing.assert_array_equal(host(kc).transpose(0, 2, 1, 3).reshape(-1, kvh, d)[:T], g[f"rope_{tag}_ko_bfloat16"])
+
+
+# --------------------------------------------------------------------------- #
+def build_paged(rng, ctxs, kvh, d, dtype, extra_blocks=5, poison=True):
+    """Random K/V for each sequence scattered into shuffled pages; unused slots
+    are poisoned with NaN to prove the kernels never let them through."""
+    nblks = [(c + 15) // 16 for c in ctxs]
+    total = sum(nblks) + extra_blocks
+    perm = rng.permutation(total).astype(np.int32)
+    max_blocks = max(max(nblks), 1) + 2
+    bt = np.zeros((len(ctxs), max_blocks), np.int32)
+    fill = np.nan if poison else 0.0
+    kc = np.full((total, kvh, 16, d), fill, np.float32)
+    vc = np.full((total, kvh, d, 16), fill, np.float32)
+    used = 0
+    for i, c in enumerate(ctxs):
+        bt[i, : nblks[i]] = perm[used: used + nblks[i]]
+        bt[i, nblks[i]:] = perm[-1]                       # never-read filler ids
+        used += nblks[i]
+        if c:
+            k, v = grid(rng, (c, kvh, d), dtype), grid(rng, (c, kvh, d), dtype)
+            slots = bt[i, np.arange(c) // 16].astype(np.int64) * 16 + np.arange(c) % 16
+            R.kv_write(k, v, slots, kc, vc)
+    return kc, vc, bt
+
+
+def attn_close(got, ref, dtype):
+    scale = np.abs(ref).max() if ref.size else 1.0
+    err = np.abs(got - ref)
+    tol = ATTN_TOL[dtype] * scale + ULP[dtype] * np.abs(ref)
+    assert not np.isnan(got).any(), "NaN in attention output"
+    assert (err <= tol).all(), f"max err {err.max():.4g} vs tol {tol.flat[err.argmax()]:.4g} (scale {scale:.3g})"
+
+
+DECODE_CTX = [1, 15, 16, 17, 31, 32, 33, 64, 127, 128, 129, 200, 255, 256, 1000, 0]
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("nh,kvh,d", [(4, 2, 64), (8, 2, 128), (32, 8, 128), (7, 1, 64), (8, 1, 128), (4, 4, 128)])
+@pytest.mark.parametrize("splits", [1, 2, 5])
+def test_paged_attn_decode(ops, dtype, nh, kvh, d, splits):
+    rng = rng_for("dec", dtype, nh, kvh, d)
+    ctxs = DECODE_CTX
+    kc, vc, bt = build_paged(rng, ctxs, kvh, d, dtype)
+    q = grid(rng, (len(ctxs), nh, d), dtype)
+    scale = d ** -0.5
+    ref = R.paged_attn_decode(q, np.nan_to_num(kc), np.nan_to_num(vc), bt, np.array(ctxs, np.int32), scale, dtype)
+    out = ops.paged_attn_decode(dev(q.reshape(len(ctxs), -1), dtype), dev(kc, dtype), dev(vc, dtype),
+                                torch.from_numpy(bt).cuda(), torch.tensor(ctxs, dtype=torch.int32, device="cuda"),
+                                nh, kvh, d, scale, num_splits=splits)
+    attn_close(host(out).reshape(len(ctxs), nh, d), ref, dtype)
+
+
+def test_paged_attn_decode_q_inside_qkv_rows(ops):
+    """q passed as a strided view of the packed QKV buffer (how the engine calls it)."""
+    dtype, nh, kvh, d = "bfloat16", 8, 2, 128
+    rng = rng_for("dec-strided")
+    ctxs = [40, 7, 129]
+    kc, vc, bt = build_paged(rng, ctxs, kvh, d, dtype)
+    qkv = grid(rng, (3, (nh + 2 * kvh) * d), dtype)
+    ref = R.paged_attn_decode(qkv[:, : nh * d].reshape(3, nh, d), np.nan_to_num(kc), np.nan_to_num(vc), bt,
+                              np.array(ctxs, np.int32), d ** -0.5, dtype)
+    qd = dev(qkv, dtype)
+    out = ops.paged_attn_decode(qd[:, : nh * d], dev(kc, dtype), dev(vc, dtype), torch.from_numpy(bt).cuda(),
+                                torch.tensor(ctxs, dtype=torch.int32, device="cuda"), nh, kvh, d, d ** -0.5)
+    attn_close(host(out).reshape(3, nh, d), ref, dtype)
+
+
+def test_paged_attn_decode_golden(ops, ops_golden):
+    """HF eager attention outputs (fp32) for single-query attention."""
+    g = ops_golden
+    for tag, nh, kvh, d in (("g2d64", 4, 2, 64), ("g4d128", 8, 2, 128), ("g7d64", 7, 1, 64), ("g8d128", 8, 1, 128)):
+        for L in g[f"attn_{tag}_ctx"]:
+            q, k, v = (g[f"attn_{tag}_dec{L}_{n}"] for n in "qkv")
+            nblk = (int(L) + 15) // 16
+            kc = np.zeros((nblk, kvh, 16, d), np.float32)
+            vc = np.zeros((nblk, kvh, d, 16), np.float32)
+            R.kv_write(k, v, np.arange(L, dtype=np.int64), kc, vc)
+            bt = np.arange(nblk, dtype=np.int32)[None]
+            out = ops.paged_attn_decode(dev(q.reshape(1, -1), "bfloat16"), dev(kc, "bfloat16"), dev(vc, "bfloat16"),
+                                        torch.from_numpy(bt).cuda(), torch.tensor([L], dtype=torch.int32, device="cuda"),
+                                        nh, kvh, d, d ** -0.5)
+            attn_close(host(out).reshape(1, nh, d), g[f"attn_{tag}_dec{L}_o"], "bfloat16")
+
+
+def test_paged_attn_decode_softmax_spike(ops):
+    """Force the online-softmax rescale: one late key dominates all earlier ones."""
+    dtype, nh, kvh, d = "bfloat16", 8, 2, 128
+    rng = rng_for("spike")
+    L = 300
+    k, v = grid(rng, (L, kvh, d), dtype, 0.5), grid(rng, (L, kvh, d), dtype)
+    q = grid(rng, (1, nh, d), dtype)
+    for pos in (5, 170, 299):
+        k2 = k.copy()
+        k2[pos] = R.round_to(8.0 * q[0, ::4][:kvh], dtype)      # huge positive score for head 0 of each group
+        nblk = (L + 15) // 16
+        kc, vc = np.zeros((nblk, kvh, 16, d), np.float32), np.zeros((nblk, kvh, d, 16), np.float32)
+        R.kv_write(k2, v, np.arange(L, dtype=np.int64), kc, vc)
+        bt = np.arange(nblk, dtype=np.int32)[None]
+        ref = R.paged_attn_decode(q, kc, vc, bt, np.array([L], np.int32), d ** -0.5, dtype)
+        out = ops.paged_attn_decode(dev(q.reshape(1, -1), dtype), dev(kc, dtype), dev(vc, dtype),
+                                    torch.from_numpy(bt).cuda(), torch.tensor([L], dtype=torch.int32, device="cuda"),
+                                    nh, kvh, d, d ** -0.5)
+        attn_close(host(out).reshape(1, nh, d), ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("nh,kvh,d", [(4, 2, 64), (8, 2, 128), (32, 8, 128), (7, 1, 64), (16, 2, 128)])
+def test_paged_attn_prefill(ops, dtype, nh, kvh, d):
+    rng = rng_for("pre", dtype, nh, kvh, d)
+    # (context_len, q_len): full prefill and chunked continuation
+    cases = [(1, 1), (5, 5), (16, 16), (17, 17), (37, 37), (128, 128), (50, 13), (200, 33), (64, 1)]
+    ctxs = [c for c, _ in cases]
+    qlens = [q for _, q in cases]
+    kc, vc, bt = build_paged(rng, ctxs, kvh, d, dtype)
+    T = sum(qlens)
+    q = grid(rng, (T, nh, d), dtype)
+    cu = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int32)
+    scale = d ** -0.5
+    ref = R.paged_attn_prefill(q, np.nan_to_num(kc), np.nan_to_num(vc), bt, cu, np.array(ctxs, np.int32), scale, dtype)
+    out = ops.paged_attn_prefill(dev(q.reshape(T, -1), dtype), dev(kc, dtype), dev(vc, dtype),
+                                 torch.from_numpy(bt).cuda(), torch.from_numpy(cu).cuda(),
+                                 torch.tensor(ctxs, dtype=torch.int32, device="cuda"), max(qlens), nh, kvh, d, scale)
+    attn_close(host(out).reshape(T, nh, d), ref, dtype)
+
+
+def test_paged_attn_prefill_golden(ops, ops_golden):
+    g = ops_golden
+    for tag, nh, kvh, d in (("g2d64", 4, 2, 64), ("g4d128", 8, 2, 128), ("g7d64", 7, 1, 64), ("g8d128", 8, 1, 128)):
+        for L, Lq in [(1, 1), (5, 5), (16, 16), (37, 37), (50, 13)]:
+            q, k, v = (g[f"attn_{tag}_pre{L}_{Lq}_{n}"] for n in "qkv")
+            nblk = (L + 15) // 16
+            kc, vc = np.zeros((nblk, kvh, 16, d), np.float32), np.zeros((nblk, kvh, d, 16), np.float32)
+            R.kv_write(k, v, np.arange(L, dtype=np.int64), kc, vc)
+            out = ops.paged_attn_prefill(dev(q.reshape(Lq, -1), "bfloat16"), dev(kc, "bfloat16"), dev(vc, "bfloat16"),
+                                         torch.arange(nblk, dtype=torch.int32, device="cuda")[None].contiguous(),
+                                         torch.tensor([0, Lq], dtype=torch.int32, device="cuda"),
+                                         torch.tensor([L], dtype=torch.int32, device="cuda"), Lq, nh, kvh, d, d ** -0.5)
+            attn_close(host(out).reshape(Lq, nh, d), g[f"attn_{tag}_pre{L}_{Lq}_o"], "bfloat16")
+
+
+def test_prefill_then_decode_consistent(ops):
+    """The last row of a prefill equals a decode step over the same cache."""
+    dtype, nh, kvh, d = "bfloat16", 8, 2, 128
+    rng = rng_for("consistency")
+    ctxs = [70, 33]
+    kc, vc, bt = build_paged(rng, ctxs, kvh, d, dtype)
+    q = grid(rng, (sum(ctxs), nh, d), dtype)
+    cu = np.array([0, 70, 103], np.int32)
+    args = (dev(kc, dtype), dev(vc, dtype), torch.from_numpy(bt).cuda())
+    cl = torch.tensor(ctxs, dtype=torch.int32, device="cuda")
+    pre = host(ops.paged_attn_prefill(dev(q.reshape(103, -1), dtype), *args, torch.from_numpy(cu).cuda(), cl, 70,
+                                      nh, kvh, d, d ** -0.5))
+    dec = host(ops.paged_attn_decode(dev(q[[69, 102]].reshape(2, -1), dtype), *args, cl, nh, kvh, d, d ** -0.5))
+    np.testing.assert_allclose(pre[[69, 102]], dec, rtol=2 ** -6, atol=2e-2)
+
+
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("T,F", [(1, 512), (32, 14336), (7, 1000), (300, 640)])
+def test_silu_and_mul(ops, dtype, T, F):
+    rng = rng_for("silu", dtype, T, F)
+    x = grid(rng, (T, 2 * F), dtype, 3.0)
+    y = ops.silu_and_mul(dev(x, dtype))
+    assert_ulp_close(host(y), R.silu_and_mul(x, dtype), dtype, 0.002)
+
+
+def test_silu_golden(ops, ops_golden):
+    y = ops.silu_and_mul(dev(ops_golden["silu_x"], "bfloat16"))
+    assert_ulp_close(host(y), ops_golden["silu_y_bfloat16"], "bfloat16", 0.002)
+
+
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("ldt", ["float32", "bfloat16", "float16"])
+@pytest.mark.parametrize("B,V", [(1, 8), (6, 1000), (32, 128256), (3, 50272), (2, 152064), (4, 1027)])
+def test_argmax(ops, ldt, B, V):
+    rng = rng_for("argmax", ldt, B, V)
+    stride = (V + 7) // 8 * 8
+    lg = (rng.standard_normal((B, V)) * 4).astype(np.float32)
+    lg = R.round_to(lg, ldt)
+    hi = float(np.abs(lg).max()) + 1.0
+    if V > 16:
+        lg[0, [5, V - 3]] = hi                           # tie -> lowest index
+        lg[B - 1, :] = 0.0
+        lg[B - 1, V // 2] = -0.0                         # signed zeros are equal -> index 0
+    ref = R.argmax_lowest(lg)
+    tdt = {"float32": torch.float32, **DT}[ldt]
+    buf = torch.full((B, stride), float("-inf"), dtype=tdt, device="cuda")
+    buf[:, :V] = torch.from_numpy(lg).to(tdt).cuda()
+    out = ops.argmax(buf[:, :V])
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)  # bit-exact indices
+
+
+def test_argmax_golden_and_nan(ops, ops_golden):
+    lg = ops_golden["argmax_logits"]
+    out = ops.argmax(torch.from_numpy(lg).cuda())
+    np.testing.assert_array_equal(out.cpu().numpy(), ops_golden["argmax_idx"])

@@ -1,0 +1,92 @@
+// Shared device helpers and host-side argument checking for libmi355_decode.so.
+// gfx950 only: wave = 64 lanes, MFMA 16x16x32 for bf16 / fp16.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "mi355_decode.h"
+
+namespace mi355 {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---- per-dtype traits: raw 16-bit word <-> float, MFMA on 8-element fragments
+struct BF16 {
+  static __device__ __forceinline__ float to_f(uint16_t u) {
+    return __uint_as_float(static_cast<uint32_t>(u) << 16);
+  }
+  static __device__ __forceinline__ uint16_t from_f(float f) {
+    __bf16 b = static_cast<__bf16>(f);  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return __builtin_bit_cast(uint16_t, b);
+  }
+  static __device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+struct F16 {
+  static __device__ __forceinline__ float to_f(uint16_t u) {
+    return static_cast<float>(__builtin_bit_cast(_Float16, u));
+  }
+  static __device__ __forceinline__ uint16_t from_f(float f) {
+    _Float16 h = static_cast<_Float16>(f);
+    return __builtin_bit_cast(uint16_t, h);
+  }
+  static __device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ float round_f(float f) {
+  return T::to_f(T::from_f(f));
+}
+
+// 8 packed 16-bit words <-> 8 floats
+template <typename T>
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = T::to_f(static_cast<uint16_t>(w[i] & 0xFFFFu));
+    f[2 * i + 1] = T::to_f(static_cast<uint16_t>(w[i] >> 16));
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    w[i] = static_cast<uint32_t>(T::from_f(f[2 * i])) |
+           (static_cast<uint32_t>(T::from_f(f[2 * i + 1])) << 16);
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---- host side ------------------------------------------------------------
+int32_t fail(int32_t code, const char* fmt, ...);
+
+#define MI355_REQUIRE(cond, code, ...)                  \
+  do {                                                  \
+    if (!(cond)) return ::mi355::fail((code), __VA_ARGS__); \
+  } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Call after a launch: turns a HIP launch error into MI355_ERR_LAUNCH.
+int32_t check_launch(const char* what);
+
+}  // namespace mi355

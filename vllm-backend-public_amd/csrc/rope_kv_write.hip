@@ -1,0 +1,133 @@
+// Rotary embedding (rotate-half pairing) on the q and k parts of the packed QKV
+// rows, fused with the paged KV-cache store.
+//
+// Work item = (token, head, chunk): 8 rotation pairs, i.e. elements
+// [8c, 8c+8) of the first half and the matching 8 of the second half of one
+// head.  q heads are rotated in place; k heads are rotated in place and stored
+// to the K page (token rows, two 16-byte stores); v heads are copied to the V
+// page, which keeps tokens along the fastest axis (16 two-byte stores at a
+// 32-byte stride -- the page is laid out for the PV MFMA operand, see
+// paged_attn_decode.hip).  All loads are 16-byte vectors; cos/sin come from a
+// precomputed table in the model dtype.  HBM-bound and small: 2 bytes in, 2 out
+// per q element, 2 in / 4 out per k element, 2 in / 2 out per v element.
+#include "common.h"
+
+namespace mi355 {
+
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kv_write_kernel(
+    uint16_t* __restrict__ qkv, int64_t qkv_stride, const int64_t* __restrict__ positions,
+    const uint16_t* __restrict__ cos_sin, int max_position, const int64_t* __restrict__ slot_mapping,
+    uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache, int num_blocks, int64_t num_tokens,
+    int num_heads, int num_kv_heads, int head_dim) {
+  const int half = head_dim >> 1;
+  const int chunks = half >> 3;  // 8 pairs per chunk
+  const int heads_total = num_heads + 2 * num_kv_heads;
+  const int64_t items = num_tokens * heads_total * chunks;
+  constexpr int BS = MI355_BLOCK_SIZE;
+
+  for (int64_t it = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; it < items;
+       it += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int c = static_cast<int>(it % chunks);
+    const int head = static_cast<int>((it / chunks) % heads_total);
+    const int64_t tok = it / (static_cast<int64_t>(chunks) * heads_total);
+
+    uint16_t* base = qkv + tok * qkv_stride + static_cast<int64_t>(head) * head_dim;
+    uint4* p1 = reinterpret_cast<uint4*>(base + 8 * c);
+    uint4* p2 = reinterpret_cast<uint4*>(base + half + 8 * c);
+    uint4 r1 = *p1, r2 = *p2;
+
+    const bool is_v = head >= num_heads + num_kv_heads;
+    if (!is_v) {
+      int64_t pos = positions[tok];
+      pos = pos < 0 ? 0 : (pos >= max_position ? max_position - 1 : pos);
+      const uint16_t* cs = cos_sin + pos * head_dim;
+      float x1[8], x2[8], co[8], si[8];
+      unpack8<T>(r1, x1);
+      unpack8<T>(r2, x2);
+      unpack8<T>(*reinterpret_cast<const uint4*>(cs + 8 * c), co);
+      unpack8<T>(*reinterpret_cast<const uint4*>(cs + half + 8 * c), si);
+      float o1[8], o2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        // each product and the sum are rounded to the model dtype
+        o1[j] = round_f<T>(x1[j] * co[j]) - round_f<T>(x2[j] * si[j]);
+        o2[j] = round_f<T>(x2[j] * co[j]) + round_f<T>(x1[j] * si[j]);
+      }
+      r1 = pack8<T>(o1);
+      r2 = pack8<T>(o2);
+      *p1 = r1;
+      *p2 = r2;
+    }
+    if (head < num_heads) continue;
+
+    const int64_t slot = slot_mapping[tok];
+    if (slot < 0 || slot >= static_cast<int64_t>(num_blocks) * BS) continue;
+    const int64_t blk = slot / BS;
+    const int off = static_cast<int>(slot % BS);
+    if (!is_v) {
+      const int kvh = head - num_heads;
+      uint16_t* dst = k_cache + ((blk * num_kv_heads + kvh) * BS + off) * head_dim;
+      *reinterpret_cast<uint4*>(dst + 8 * c) = r1;
+      *reinterpret_cast<uint4*>(dst + half + 8 * c) = r2;
+    } else {
+      const int kvh = head - num_heads - num_kv_heads;
+      uint16_t* dst = v_cache + (blk * num_kv_heads + kvh) * head_dim * BS + off;
+      const uint32_t w1[4] = {r1.x, r1.y, r1.z, r1.w};
+      const uint32_t w2[4] = {r2.x, r2.y, r2.z, r2.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint16_t e1 = static_cast<uint16_t>(j & 1 ? w1[j >> 1] >> 16 : w1[j >> 1] & 0xFFFFu);
+        const uint16_t e2 = static_cast<uint16_t>(j & 1 ? w2[j >> 1] >> 16 : w2[j >> 1] & 0xFFFFu);
+        dst[static_cast<int64_t>(8 * c + j) * BS] = e1;
+        dst[static_cast<int64_t>(half + 8 * c + j) * BS] = e2;
+      }
+    }
+  }
+}
+
+}  // namespace mi355
+
+extern "C" int32_t mi355_rope_kv_write(void* qkv, int64_t qkv_stride, const int64_t* positions,
+                                       const void* cos_sin, int32_t max_position,
+                                       const int64_t* slot_mapping, void* k_cache, void* v_cache,
+                                       int32_t num_blocks, int64_t num_tokens, int32_t num_heads,
+                                       int32_t num_kv_heads, int32_t head_dim, int32_t dtype,
+                                       void* stream) {
+  using namespace mi355;
+  const char* name = "mi355_rope_kv_write";
+  MI355_REQUIRE(qkv && positions && cos_sin && slot_mapping && k_cache && v_cache, MI355_ERR_INVALID,
+                "%s: null pointer", name);
+  MI355_REQUIRE(num_tokens >= 0 && num_tokens <= 0x7FFFFFFF, MI355_ERR_INVALID,
+                "%s: num_tokens %lld out of range", name, (long long)num_tokens);
+  MI355_REQUIRE(head_dim > 0 && head_dim % 16 == 0 && head_dim <= 256, MI355_ERR_UNSUPPORTED,
+                "%s: head_dim %d must be a multiple of 16, at most 256", name, head_dim);
+  MI355_REQUIRE(num_heads > 0 && num_kv_heads > 0 && num_blocks > 0 && max_position > 0, MI355_ERR_INVALID,
+                "%s: num_heads/num_kv_heads/num_blocks/max_position must be positive", name);
+  const int64_t width = static_cast<int64_t>(num_heads + 2 * num_kv_heads) * head_dim;
+  MI355_REQUIRE(qkv_stride >= width && qkv_stride % 8 == 0, MI355_ERR_INVALID,
+                "%s: qkv_stride %lld must be >= %lld and a multiple of 8", name, (long long)qkv_stride,
+                (long long)width);
+  MI355_REQUIRE(aligned16(qkv) && aligned16(cos_sin) && aligned16(k_cache) && aligned16(v_cache),
+                MI355_ERR_INVALID, "%s: pointers must be 16-byte aligned", name);
+  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED,
+                "%s: dtype %d not supported (bf16/fp16 only)", name, dtype);
+  if (num_tokens == 0) return MI355_OK;
+
+  const int64_t items = num_tokens * (num_heads + 2 * num_kv_heads) * (head_dim / 16);
+  int64_t blocks = (items + 255) / 256;
+  if (blocks > 8192) blocks = 8192;  // grid-stride beyond 32 workgroups per CU
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  if (dtype == MI355_BF16)
+    hipLaunchKernelGGL((rope_kv_write_kernel<BF16>), grid, block, 0, s, static_cast<uint16_t*>(qkv),
+                       qkv_stride, positions, static_cast<const uint16_t*>(cos_sin), max_position,
+                       slot_mapping, static_cast<uint16_t*>(k_cache), static_cast<uint16_t*>(v_cache),
+                       num_blocks, num_tokens, num_heads, num_kv_heads, head_dim);
+  else
+    hipLaunchKernelGGL((rope_kv_write_kernel<F16>), grid, block, 0, s, static_cast<uint16_t*>(qkv),
+                       qkv_stride, positions, static_cast<const uint16_t*>(cos_sin), max_position,
+                       slot_mapping, static_cast<uint16_t*>(k_cache), static_cast<uint16_t*>(v_cache),
+                       num_blocks, num_tokens, num_heads, num_kv_heads, head_dim);
+  return check_launch(name);
+}

@@ -1,0 +1,64 @@
+"""ctypes binding of libmi355_decode.so (C ABI declared in include/mi355_decode.h).
+
+The library is the product's only compute path for the hot operators; there is
+no CPU or framework fallback.  If the shared object is missing or a symbol
+cannot be bound, importing this module raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("MI355_DECODE_LIB", os.path.join(_HERE, "libmi355_decode.so"))
+
+ABI_VERSION = 1
+BLOCK_SIZE = 16
+DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
+
+
+class Mi355Error(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C vllm-backend-public_amd/csrc` "
+            "(or __graft_entry__.build()); the engine has no fallback path")
+    lib = ctypes.CDLL(LIB_PATH)
+    P, I32, I64, F = c_void_p, c_int32, c_int64, c_float
+    sigs = {
+        "mi355_abi_version": (I32, []),
+        "mi355_last_error": (c_char_p, []),
+        "mi355_target_arch": (c_char_p, []),
+        "mi355_rms_norm": (I32, [P, P, P, I64, I32, I64, I64, F, I32, P]),
+        "mi355_fused_add_rms_norm": (I32, [P, P, P, P, I64, I32, I64, I64, I64, F, I32, P]),
+        "mi355_rope_kv_write": (I32, [P, I64, P, P, I32, P, P, P, I32, I64, I32, I32, I32, I32, P]),
+        "mi355_paged_attn_decode_workspace": (I64, [I32, I32, I32, I32]),
+        "mi355_paged_attn_decode": (I32, [P, P, I64, P, P, I32, P, I32, P, I32, I32, I32, I32, F, I32, P,
+                                          I64, I32, P]),
+        "mi355_paged_attn_prefill": (I32, [P, I64, P, I64, P, P, I32, P, I32, P, P, I32, I32, I32, I32, I32,
+                                           F, I32, P]),
+        "mi355_silu_and_mul": (I32, [P, P, I64, I64, I32, I32, P]),
+        "mi355_argmax": (I32, [P, P, I64, I32, I32, I32, P]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype, fn.argtypes = res, args
+    got = lib.mi355_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {got}, host expects {ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+EXPORTS = ("mi355_abi_version", "mi355_last_error", "mi355_target_arch", "mi355_rms_norm",
+           "mi355_fused_add_rms_norm", "mi355_rope_kv_write", "mi355_paged_attn_decode_workspace",
+           "mi355_paged_attn_decode", "mi355_paged_attn_prefill", "mi355_silu_and_mul", "mi355_argmax")
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise Mi355Error(f"status {status}: {lib.mi355_last_error().decode()}")

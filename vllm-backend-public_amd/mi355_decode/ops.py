@@ -1,0 +1,190 @@
+"""Tensor-level wrappers over the C ABI (libmi355_decode.so).
+
+PyTorch is used only as the owner of device memory and streams: each wrapper
+checks dtype/layout, then passes raw device pointers, sizes and the current HIP
+stream to the library.  Every call is asynchronous on
+``torch.cuda.current_stream()`` and allocates nothing unless it has to return a
+new tensor (pass ``out=`` to avoid that, e.g. under HIP graph capture).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import BLOCK_SIZE, check, lib
+
+_DT = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16, torch.float32: _lib.DTYPE_F32}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (got {t.device})")
+
+
+def _dt16(t: torch.Tensor, name: str) -> int:
+    _dev(t, name)
+    if t.dtype not in (torch.bfloat16, torch.float16):
+        raise TypeError(f"{name}: dtype {t.dtype} not supported (bfloat16/float16)")
+    return _DT[t.dtype]
+
+
+def _rows(t: torch.Tensor, name: str) -> int:
+    """Row stride (elements) of a 2-D view whose last dim is contiguous."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name} must be 2-D with a contiguous last dim (shape {tuple(t.shape)}, "
+                         f"strides {t.stride()})")
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: torch.Tensor | None = None):
+    dt = _dt16(x, "x")
+    _dev(weight, "weight")
+    if weight.dtype != x.dtype or weight.numel() != x.shape[1] or not weight.is_contiguous():
+        raise ValueError("weight must be contiguous [hidden] in the dtype of x")
+    if out is None:
+        out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    check(lib.mi355_rms_norm(out.data_ptr(), x.data_ptr(), weight.data_ptr(), x.shape[0], x.shape[1],
+                             _rows(x, "x"), _rows(out, "out"), float(eps), dt, _stream()))
+    return out
+
+
+def fused_add_rms_norm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                       out: torch.Tensor | None = None):
+    """residual <- x + residual (in place); returns rms_norm(residual).  ``out`` defaults to ``x``."""
+    dt = _dt16(x, "x")
+    _dev(residual, "residual"), _dev(weight, "weight")
+    if residual.dtype != x.dtype or residual.shape != x.shape or weight.dtype != x.dtype:
+        raise ValueError("residual must match x; weight must have the dtype of x")
+    if weight.numel() != x.shape[1] or not weight.is_contiguous():
+        raise ValueError("weight must be contiguous [hidden]")
+    if out is None:
+        out = x
+    check(lib.mi355_fused_add_rms_norm(out.data_ptr(), x.data_ptr(), residual.data_ptr(), weight.data_ptr(),
+                                       x.shape[0], x.shape[1], _rows(x, "x"), _rows(out, "out"),
+                                       _rows(residual, "residual"), float(eps), dt, _stream()))
+    return out
+
+
+def rope_kv_write(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: torch.Tensor,
+                  slot_mapping: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                  num_heads: int, num_kv_heads: int, head_dim: int) -> None:
+    """In-place rotary embedding on the q|k parts of ``qkv`` + paged store of k, v.
+    k_cache [blocks, kv_heads, 16, head_dim]; v_cache [blocks, kv_heads, head_dim, 16]."""
+    dt = _dt16(qkv, "qkv")
+    T = qkv.shape[0]
+    for t, n in ((positions, "positions"), (slot_mapping, "slot_mapping")):
+        _dev(t, n)
+        if t.dtype != torch.int64 or t.numel() != T or not t.is_contiguous():
+            raise ValueError(f"{n} must be contiguous int64 [num_tokens]")
+    nb = k_cache.shape[0]
+    if (tuple(k_cache.shape) != (nb, num_kv_heads, BLOCK_SIZE, head_dim)
+            or tuple(v_cache.shape) != (nb, num_kv_heads, head_dim, BLOCK_SIZE)
+            or not k_cache.is_contiguous() or not v_cache.is_contiguous()
+            or k_cache.dtype != qkv.dtype or v_cache.dtype != qkv.dtype):
+        raise ValueError("k_cache/v_cache must be contiguous [blocks, kv_heads, 16, d] / [blocks, kv_heads, d, 16]")
+    if cos_sin.dtype != qkv.dtype or cos_sin.dim() != 2 or cos_sin.shape[1] != head_dim or not cos_sin.is_contiguous():
+        raise ValueError("cos_sin must be contiguous [max_position, head_dim] in the dtype of qkv")
+    if qkv.shape[1] != (num_heads + 2 * num_kv_heads) * head_dim:
+        raise ValueError("qkv width must be (num_heads + 2*num_kv_heads) * head_dim")
+    check(lib.mi355_rope_kv_write(qkv.data_ptr(), _rows(qkv, "qkv"), positions.data_ptr(), cos_sin.data_ptr(),
+                                  cos_sin.shape[0], slot_mapping.data_ptr(), k_cache.data_ptr(),
+                                  v_cache.data_ptr(), nb, T, num_heads, num_kv_heads, head_dim, dt, _stream()))
+
+
+def decode_workspace_bytes(num_seqs: int, num_heads: int, head_dim: int, num_splits: int) -> int:
+    return int(lib.mi355_paged_attn_decode_workspace(num_seqs, num_heads, head_dim, num_splits))
+
+
+def _check_cache(q, k_cache, v_cache, block_tables, num_kv_heads, head_dim):
+    nb = k_cache.shape[0]
+    if (tuple(k_cache.shape) != (nb, num_kv_heads, BLOCK_SIZE, head_dim)
+            or tuple(v_cache.shape) != (nb, num_kv_heads, head_dim, BLOCK_SIZE)
+            or not k_cache.is_contiguous() or not v_cache.is_contiguous()
+            or k_cache.dtype != q.dtype or v_cache.dtype != q.dtype):
+        raise ValueError("k_cache/v_cache must be contiguous [blocks, kv_heads, 16, d] / [blocks, kv_heads, d, 16]")
+    _dev(block_tables, "block_tables")
+    if block_tables.dtype != torch.int32 or block_tables.dim() != 2 or not block_tables.is_contiguous():
+        raise ValueError("block_tables must be contiguous int32 [num_seqs, max_blocks]")
+    return nb
+
+
+def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                      block_tables: torch.Tensor, context_lens: torch.Tensor, num_heads: int,
+                      num_kv_heads: int, head_dim: int, scale: float, num_splits: int = 1,
+                      workspace: torch.Tensor | None = None, out: torch.Tensor | None = None):
+    """q: 2-D view [num_seqs, >= num_heads*head_dim] (e.g. the q part of the qkv rows)."""
+    dt = _dt16(q, "q")
+    B = q.shape[0]
+    nb = _check_cache(q, k_cache, v_cache, block_tables, num_kv_heads, head_dim)
+    _dev(context_lens, "context_lens")
+    if context_lens.dtype != torch.int32 or context_lens.numel() != B or not context_lens.is_contiguous():
+        raise ValueError("context_lens must be contiguous int32 [num_seqs]")
+    if block_tables.shape[0] != B:
+        raise ValueError("block_tables rows must equal num_seqs")
+    if out is None:
+        out = torch.empty((B, num_heads * head_dim), dtype=q.dtype, device=q.device)
+    elif not out.is_contiguous() or out.numel() != B * num_heads * head_dim or out.dtype != q.dtype:
+        raise ValueError("out must be contiguous [num_seqs, num_heads*head_dim]")
+    ws_ptr, ws_bytes = 0, 0
+    if num_splits > 1:
+        need = decode_workspace_bytes(B, num_heads, head_dim, num_splits)
+        if workspace is None:
+            workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
+        ws_ptr, ws_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    check(lib.mi355_paged_attn_decode(out.data_ptr(), q.data_ptr(), _rows(q, "q"), k_cache.data_ptr(),
+                                      v_cache.data_ptr(), nb, block_tables.data_ptr(), block_tables.shape[1],
+                                      context_lens.data_ptr(), B, num_heads, num_kv_heads, head_dim,
+                                      float(scale), num_splits, ws_ptr, ws_bytes, dt, _stream()))
+    return out
+
+
+def paged_attn_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                       block_tables: torch.Tensor, cu_seqlens: torch.Tensor, context_lens: torch.Tensor,
+                       max_q_len: int, num_heads: int, num_kv_heads: int, head_dim: int, scale: float,
+                       out: torch.Tensor | None = None):
+    dt = _dt16(q, "q")
+    T = q.shape[0]
+    nb = _check_cache(q, k_cache, v_cache, block_tables, num_kv_heads, head_dim)
+    S = block_tables.shape[0]
+    for t, n, cnt in ((cu_seqlens, "cu_seqlens", S + 1), (context_lens, "context_lens", S)):
+        _dev(t, n)
+        if t.dtype != torch.int32 or t.numel() != cnt or not t.is_contiguous():
+            raise ValueError(f"{n} must be contiguous int32 [{cnt}]")
+    if out is None:
+        out = torch.empty((T, num_heads * head_dim), dtype=q.dtype, device=q.device)
+    check(lib.mi355_paged_attn_prefill(out.data_ptr(), _rows(out, "out"), q.data_ptr(), _rows(q, "q"),
+                                       k_cache.data_ptr(), v_cache.data_ptr(), nb, block_tables.data_ptr(),
+                                       block_tables.shape[1], cu_seqlens.data_ptr(), context_lens.data_ptr(),
+                                       S, int(max_q_len), num_heads, num_kv_heads, head_dim, float(scale), dt,
+                                       _stream()))
+    return out
+
+
+def silu_and_mul(x: torch.Tensor, out: torch.Tensor | None = None):
+    dt = _dt16(x, "x")
+    T, two_f = x.shape
+    if two_f % 2:
+        raise ValueError("x must be [num_tokens, 2*inter]")
+    inter = two_f // 2
+    if out is None:
+        out = torch.empty((T, inter), dtype=x.dtype, device=x.device)
+    elif not out.is_contiguous() or tuple(out.shape) != (T, inter):
+        raise ValueError("out must be contiguous [num_tokens, inter]")
+    check(lib.mi355_silu_and_mul(out.data_ptr(), x.data_ptr(), _rows(x, "x"), T, inter, dt, _stream()))
+    return out
+
+
+def argmax(logits: torch.Tensor, out: torch.Tensor | None = None):
+    _dev(logits, "logits")
+    if logits.dtype not in _DT:
+        raise TypeError(f"logits dtype {logits.dtype} not supported")
+    B, V = logits.shape
+    if out is None:
+        out = torch.empty(B, dtype=torch.int64, device=logits.device)
+    check(lib.mi355_argmax(out.data_ptr(), logits.data_ptr(), _rows(logits, "logits"), B, V,
+                           _DT[logits.dtype], _stream()))
+    return out
