@@ -50,7 +50,10 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(
       float o1[8], o2[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        // each product and the sum are rounded to the model dtype
+        // Each product and the sum are rounded to the model dtype.  Contraction
+        // must stay off here: with fp16 the compiler lowers these to half
+        // arithmetic and would fuse mul + sub into one fma, dropping a rounding.
+#pragma clang fp contract(off)
         o1[j] = round_f<T>(x1[j] * co[j]) - round_f<T>(x2[j] * si[j]);
         o2[j] = round_f<T>(x2[j] * co[j]) + round_f<T>(x1[j] * si[j]);
       }

@@ -1,0 +1,168 @@
+"""Model and engine configuration.
+
+``EngineArgs`` mirrors the engine CLI the reference harness generates
+(benchmark-vllm/vllm_templates.py:50-87, vllm_manager.py:399-416): same flag
+names and defaults as the engine it launches, so a `VLLMConfig`
+(benchmark-vllm/models.py:5-31) maps onto it field by field.
+``ModelConfig`` is read from the HF-style ``config.json`` of a local model
+directory (weights are served from a local path, benchmark-mlflow/vllm_processor.py:29).
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass, field
+from typing import Any, Optional
+
+SUPPORTED_ARCHS = ("LlamaForCausalLM", "Qwen2ForCausalLM", "MistralForCausalLM")
+
+# Well-known geometries, used when --model names one of them and no local
+# config.json exists (synthetic-weight benchmarking; there is no network).
+KNOWN_MODELS = {
+    "llama-3-8b": dict(architectures=["LlamaForCausalLM"], vocab_size=128256, hidden_size=4096,
+                       intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
+                       num_key_value_heads=8, rope_theta=500000.0, rms_norm_eps=1e-5,
+                       max_position_embeddings=8192, tie_word_embeddings=False),
+    "llama-3-70b": dict(architectures=["LlamaForCausalLM"], vocab_size=128256, hidden_size=8192,
+                        intermediate_size=28672, num_hidden_layers=80, num_attention_heads=64,
+                        num_key_value_heads=8, rope_theta=500000.0, rms_norm_eps=1e-5,
+                        max_position_embeddings=8192, tie_word_embeddings=False),
+    "qwen2-7b": dict(architectures=["Qwen2ForCausalLM"], vocab_size=152064, hidden_size=3584,
+                     intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28,
+                     num_key_value_heads=4, rope_theta=1000000.0, rms_norm_eps=1e-6,
+                     max_position_embeddings=32768, tie_word_embeddings=False),
+}
+
+
+def _known_key(name: str) -> Optional[str]:
+    n = os.path.basename(name.rstrip("/")).lower().replace("meta-", "").replace("_", "-")
+    for key in KNOWN_MODELS:
+        if key in n or key.replace("-", "") in n.replace("-", ""):
+            return key
+    return None
+
+
+@dataclass
+class ModelConfig:
+    architecture: str
+    vocab_size: int
+    hidden_size: int
+    intermediate_size: int
+    num_hidden_layers: int
+    num_attention_heads: int
+    num_key_value_heads: int
+    head_dim: int
+    rope_theta: float
+    rope_scaling: Optional[dict]
+    rms_norm_eps: float
+    max_position_embeddings: int
+    tie_word_embeddings: bool
+    attention_bias: bool
+    bos_token_id: Optional[int] = None
+    eos_token_id: Any = None
+
+    @classmethod
+    def from_dict(cls, d: dict) -> "ModelConfig":
+        archs = d.get("architectures") or ["LlamaForCausalLM"]
+        arch = archs[0]
+        if arch not in SUPPORTED_ARCHS:
+            raise ValueError(f"architecture {arch!r} is not supported (supported: {SUPPORTED_ARCHS})")
+        nh = d["num_attention_heads"]
+        rope_params = d.get("rope_parameters") or {}
+        rope_scaling = d.get("rope_scaling")
+        if rope_scaling is None and rope_params.get("rope_type", "default") != "default":
+            rope_scaling = rope_params
+        if rope_scaling is not None:
+            kind = rope_scaling.get("rope_type", rope_scaling.get("type", "default"))
+            if kind == "default":
+                rope_scaling = None
+            elif kind != "llama3":
+                raise ValueError(f"rope scaling {kind!r} is not supported (default, llama3)")
+        return cls(
+            architecture=arch,
+            vocab_size=d["vocab_size"],
+            hidden_size=d["hidden_size"],
+            intermediate_size=d["intermediate_size"],
+            num_hidden_layers=d["num_hidden_layers"],
+            num_attention_heads=nh,
+            num_key_value_heads=d.get("num_key_value_heads") or nh,
+            head_dim=d.get("head_dim") or d["hidden_size"] // nh,
+            rope_theta=float(d.get("rope_theta") or rope_params.get("rope_theta") or 10000.0),
+            rope_scaling=rope_scaling,
+            rms_norm_eps=float(d.get("rms_norm_eps", 1e-6)),
+            max_position_embeddings=int(d.get("max_position_embeddings", 4096)),
+            tie_word_embeddings=bool(d.get("tie_word_embeddings", False)),
+            # Qwen2 always carries a bias on q/k/v; Llama only if attention_bias is set
+            attention_bias=bool(d.get("attention_bias", arch == "Qwen2ForCausalLM")),
+            bos_token_id=d.get("bos_token_id"),
+            eos_token_id=d.get("eos_token_id"),
+        )
+
+    @classmethod
+    def from_pretrained(cls, model: str) -> "ModelConfig":
+        """`model` is a local directory with config.json, or the name of a known
+        geometry (then weights can only be synthetic)."""
+        path = os.path.join(model, "config.json")
+        if os.path.isfile(path):
+            with open(path) as f:
+                return cls.from_dict(json.load(f))
+        key = _known_key(model)
+        if key is not None:
+            return cls.from_dict(KNOWN_MODELS[key])
+        raise FileNotFoundError(
+            f"{model!r}: no config.json there and not a built-in geometry ({sorted(KNOWN_MODELS)}); "
+            "models are loaded from a local directory, nothing is downloaded")
+
+    def num_params(self) -> int:
+        H, F, V, L = self.hidden_size, self.intermediate_size, self.vocab_size, self.num_hidden_layers
+        qkv = (self.num_attention_heads + 2 * self.num_key_value_heads) * self.head_dim * H
+        o = self.num_attention_heads * self.head_dim * H
+        per_layer = qkv + o + 3 * F * H + 2 * H
+        return L * per_layer + V * H * (1 if self.tie_word_embeddings else 2) + H
+
+
+_DTYPES = {"auto": "bfloat16", "bfloat16": "bfloat16", "bf16": "bfloat16", "half": "float16",
+           "float16": "float16", "fp16": "float16", "float": "float32", "float32": "float32"}
+
+
+@dataclass
+class EngineArgs:
+    model: str
+    served_model_name: Optional[str] = None
+    dtype: str = "auto"
+    max_model_len: Optional[int] = None
+    max_num_seqs: int = 256
+    max_num_batched_tokens: int = 8192
+    block_size: int = 16
+    gpu_memory_utilization: float = 0.9
+    tensor_parallel_size: int = 1
+    pipeline_parallel_size: int = 1
+    quantization: Optional[str] = None
+    load_format: str = "auto"
+    seed: int = 0
+    enforce_eager: bool = False
+    trust_remote_code: bool = False
+    device: str = "auto"
+    num_layers_override: Optional[int] = None      # testing / bounded benchmarks only
+    extra: dict = field(default_factory=dict)      # accepted-and-ignored engine flags
+
+    def resolved_dtype(self) -> str:
+        """The 16-bit arithmetic type the kernels run in.  float32 requests are
+        served in bfloat16 (same exponent range); the kernels have no fp32 path."""
+        key = (self.dtype or "auto").lower()
+        if key not in _DTYPES:
+            raise ValueError(f"--dtype {self.dtype!r} not understood")
+        dt = _DTYPES[key]
+        return "bfloat16" if dt == "float32" else dt
+
+    def validate(self) -> None:
+        if self.pipeline_parallel_size != 1:
+            raise ValueError("--pipeline-parallel-size > 1 is not supported: this engine shards attention "
+                             "heads across GPUs (tensor parallel) and does not pipeline layers")
+        if self.tensor_parallel_size < 1:
+            raise ValueError("--tensor-parallel-size must be >= 1")
+        if self.quantization not in (None, "", "none", "fp8"):
+            raise ValueError(f"--quantization {self.quantization!r} is not supported (fp8 or none)")
+        if self.max_num_seqs < 1:
+            raise ValueError("--max-num-seqs must be >= 1")
+        self.resolved_dtype()
