@@ -1,0 +1,230 @@
+"""Host logic of the engine (page allocator, scheduler, chunked prefill,
+preemption + recompute, stop conditions) on CPU, with a test double standing in
+for the GPU model runner.
+
+The double keeps a "KV cache" of token ids addressed exactly like the real one
+(slot = block * 16 + offset, read back through block tables and context
+lengths) and emits next = f(all tokens in the context).  Any bookkeeping error
+-- wrong slot, stale block table, lost token after a preemption, bad chunk
+boundary -- changes the generated ids, which are checked against a plain
+sequential evaluation of f."""
+import numpy as np
+import pytest
+
+from mi355_decode.engine import BlockAllocator, LLMEngine, NoFreeBlocks
+from mi355_decode.sampling_params import SamplingParams
+
+V = 1000
+
+
+def next_token(history):
+    h = 7
+    for i, t in enumerate(history):
+        h = (h * 31 + t * (i + 1) + 3) % 1000003
+    return h % V
+
+
+def reference(prompt, n, eos=None):
+    out = []
+    hist = list(prompt)
+    for _ in range(n):
+        t = next_token(hist)
+        out.append(t)
+        hist.append(t)
+        if eos is not None and t == eos:
+            break
+    return out
+
+
+class FakeRunner:
+    device = "cpu"
+
+    def __init__(self, num_blocks, max_num_seqs, max_model_len):
+        self.num_blocks, self.max_num_seqs = num_blocks, max_num_seqs
+        self.max_blocks = (max_model_len + 15) // 16
+        self.V = V
+        self.cache = np.full(num_blocks * 16, -1, dtype=np.int64)
+        B = max_num_seqs
+        self.h64 = np.zeros(3 * B, dtype=np.int64)
+        self.h32 = np.zeros(B + B * self.max_blocks, dtype=np.int32)
+        self.decode_batches, self.prefill_tokens = [], []
+
+    def host_inputs(self):
+        return self.h64, self.h32
+
+    def _context(self, bt_row, ctx):
+        idx = np.arange(ctx)
+        toks = self.cache[bt_row[idx // 16].astype(np.int64) * 16 + idx % 16]
+        assert (toks >= 0).all(), "read a slot that was never written"
+        return toks.tolist()
+
+    def run_decode(self, n):
+        B = self.max_num_seqs
+        ids, pos, slots = self.h64[:B], self.h64[B:2 * B], self.h64[2 * B:]
+        ctx, bt = self.h32[:B], self.h32[B:].reshape(B, self.max_blocks)
+        assert (slots[n:] == -1).all() and (ctx[n:] == 0).all(), "padding rows must be neutral"
+        out = []
+        for i in range(n):
+            assert ctx[i] == pos[i] + 1
+            self.cache[slots[i]] = ids[i]
+            out.append(next_token(self._context(bt[i], int(ctx[i]))))
+        self.decode_batches.append(n)
+        return out
+
+    def run_prefill(self, token_ids, positions, slot_mapping, block_tables, cu_seqlens, context_lens, max_q_len):
+        assert len(token_ids) == len(positions) == len(slot_mapping) == cu_seqlens[-1]
+        self.cache[slot_mapping] = token_ids
+        out = []
+        for i in range(len(context_lens)):
+            qlen = cu_seqlens[i + 1] - cu_seqlens[i]
+            assert qlen <= max_q_len
+            # the chunk's positions are the last qlen positions of the context
+            np.testing.assert_array_equal(positions[cu_seqlens[i]:cu_seqlens[i + 1]],
+                                          np.arange(context_lens[i] - qlen, context_lens[i]))
+            out.append(next_token(self._context(block_tables[i], int(context_lens[i]))))
+        self.prefill_tokens.append(int(cu_seqlens[-1]))
+        return out
+
+
+def run(engine):
+    got = {}
+    steps = 0
+    while engine.has_unfinished():
+        for o in engine.step():
+            got.setdefault(o.request_id, []).extend(o.new_token_ids)
+            if o.finished:
+                got[o.request_id + ":reason"] = o.finish_reason
+        steps += 1
+        assert steps < 10000
+    return got
+
+
+def make_engine(num_blocks=64, max_num_seqs=4, max_model_len=256, max_tokens=64, eos=None):
+    runner = FakeRunner(num_blocks, max_num_seqs, max_model_len)
+    return LLMEngine(runner, max_num_seqs, max_tokens, max_model_len, eos_token_ids=eos), runner
+
+
+def prompts(n, rng, lo=1, hi=60):
+    return [rng.integers(0, V, size=int(rng.integers(lo, hi))).tolist() for _ in range(n)]
+
+
+def test_block_allocator():
+    a = BlockAllocator(4)
+    x = a.allocate(3)
+    assert sorted(x) == [0, 1, 2] and a.num_free == 1
+    with pytest.raises(NoFreeBlocks):
+        a.allocate(2)
+    a.free(x)
+    assert a.num_free == 4 and sorted(a.allocate(4)) == [0, 1, 2, 3]
+
+
+def test_generation_matches_sequential_reference():
+    rng = np.random.default_rng(0)
+    eng, runner = make_engine()
+    ps = prompts(10, rng)
+    for i, p in enumerate(ps):
+        eng.add_request(f"r{i}", p, SamplingParams(max_tokens=20, temperature=0.0))
+    got = run(eng)
+    for i, p in enumerate(ps):
+        assert got[f"r{i}"] == reference(p, 20)
+        assert got[f"r{i}:reason"] == "length"
+    assert max(runner.decode_batches) == 4                      # max_num_seqs respected
+    assert eng.alloc.num_free == eng.alloc.num_blocks            # every page returned
+
+
+def test_chunked_prefill_and_token_budget():
+    rng = np.random.default_rng(1)
+    eng, runner = make_engine(max_tokens=16, max_model_len=512, num_blocks=128)
+    ps = [rng.integers(0, V, size=n).tolist() for n in (100, 3, 47, 16, 17)]
+    for i, p in enumerate(ps):
+        eng.add_request(f"r{i}", p, SamplingParams(max_tokens=5, temperature=0.0))
+    got = run(eng)
+    for i, p in enumerate(ps):
+        assert got[f"r{i}"] == reference(p, 5)
+    assert max(runner.prefill_tokens) <= 16                      # never above max_num_batched_tokens
+
+
+def test_preemption_recomputes_and_results_are_unchanged():
+    rng = np.random.default_rng(2)
+    # 3 sequences of up to 40+60 tokens need up to 21 pages; give 12 so decode runs out
+    eng, runner = make_engine(num_blocks=12, max_num_seqs=3, max_model_len=128)
+    ps = [rng.integers(0, V, size=40).tolist() for _ in range(3)]
+    for i, p in enumerate(ps):
+        eng.add_request(f"r{i}", p, SamplingParams(max_tokens=60, temperature=0.0))
+    got = run(eng)
+    assert eng.stats["preemptions"] > 0
+    for i, p in enumerate(ps):
+        assert got[f"r{i}"] == reference(p, 60)
+    assert eng.alloc.num_free == 12
+
+
+def test_stop_conditions():
+    rng = np.random.default_rng(3)
+    p = rng.integers(0, V, size=9).tolist()
+    full = reference(p, 30)
+    eos = full[4]
+    first = full.index(eos)                       # eos may also occur earlier
+    eng, _ = make_engine(eos=[eos])
+    eng.add_request("a", p, SamplingParams(max_tokens=30, temperature=0.0))
+    eng.add_request("b", p, SamplingParams(max_tokens=30, temperature=0.0, ignore_eos=True))
+    eng.add_request("c", p, SamplingParams(max_tokens=30, temperature=0.0, stop_token_ids=[full[7]], ignore_eos=True))
+    eng.add_request("d", p, SamplingParams(max_tokens=30, temperature=0.0, min_tokens=first + 2))
+    got = run(eng)
+    assert got["a"] == full[: first + 1] and got["a:reason"] == "stop"
+    assert got["b"] == full and got["b:reason"] == "length"
+    assert got["c"] == full[: full.index(full[7]) + 1] and got["c:reason"] == "stop"
+    assert len(got["d"]) >= first + 2
+
+
+def test_max_model_len_truncates_generation():
+    eng, _ = make_engine(max_model_len=32)
+    p = list(range(20))
+    eng.add_request("a", p, SamplingParams(max_tokens=100, temperature=0.0))
+    got = run(eng)
+    assert len(got["a"]) == 12 and got["a:reason"] == "length"     # 20 + 12 == max_model_len
+
+
+def test_request_validation():
+    eng, _ = make_engine(max_model_len=32)
+    with pytest.raises(ValueError, match="empty"):
+        eng.add_request("a", [], SamplingParams())
+    with pytest.raises(ValueError, match="max_model_len"):
+        eng.add_request("a", list(range(32)), SamplingParams())
+    with pytest.raises(ValueError, match="vocabulary"):
+        eng.add_request("a", [V], SamplingParams())
+    eng.add_request("a", [1], SamplingParams())
+    with pytest.raises(ValueError, match="duplicate"):
+        eng.add_request("a", [1], SamplingParams())
+    with pytest.raises(ValueError):
+        SamplingParams(max_tokens=0)
+    with pytest.raises(ValueError):
+        SamplingParams(top_p=0.0)
+
+
+def test_abort_frees_pages():
+    eng, _ = make_engine()
+    eng.add_request("a", list(range(40)), SamplingParams(max_tokens=50, temperature=0.0))
+    eng.add_request("b", list(range(10)), SamplingParams(max_tokens=5, temperature=0.0))
+    early = []
+    for _ in range(2):
+        early += [t for o in eng.step() if o.request_id == "b" for t in o.new_token_ids]
+    eng.abort_request("a")
+    got = run(eng)
+    assert early + got["b"] == reference(list(range(10)), 5)
+    assert eng.alloc.num_free == eng.alloc.num_blocks
+
+
+def test_late_arrivals_join_running_batch():
+    rng = np.random.default_rng(4)
+    eng, runner = make_engine(max_num_seqs=8)
+    ps = prompts(6, rng)
+    got = {}
+    for i, p in enumerate(ps):
+        eng.add_request(f"r{i}", p, SamplingParams(max_tokens=12, temperature=0.0))
+        for o in eng.step():                       # one step between arrivals
+            got.setdefault(o.request_id, []).extend(o.new_token_ids)
+    for k, v in run(eng).items():
+        if not k.endswith(":reason"):
+            got.setdefault(k, []).extend(v)
+    for i, p in enumerate(ps):
+        assert got[f"r{i}"] == reference(p, 12)

@@ -1,0 +1,118 @@
+"""Engine construction from EngineArgs and an offline ``LLM.generate`` front end
+(same role and names as the offline entry point of the engine the harness
+launches; the HTTP server in entrypoints/ drives the same LLMEngine)."""
+from __future__ import annotations
+
+import logging
+import os
+from typing import List, Optional
+
+import torch
+
+from ._lib import BLOCK_SIZE
+from .config import EngineArgs, ModelConfig
+from .engine import LLMEngine
+from .model_runner import ModelRunner
+from .sampling_params import SamplingParams
+from . import weights as W
+
+log = logging.getLogger("mi355_decode")
+
+TORCH_DTYPE = {"bfloat16": torch.bfloat16, "float16": torch.float16}
+
+
+def init_distributed(tp_size: int):
+    """One process per GPU.  Returns (rank, world, device, group)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if tp_size > 1:
+        if world != tp_size:
+            raise RuntimeError(f"--tensor-parallel-size {tp_size} needs {tp_size} processes "
+                               f"(WORLD_SIZE={world}); launch with torch.distributed.run")
+        device = torch.device("cuda", local)
+        torch.cuda.set_device(device)
+        if not torch.distributed.is_initialized():
+            torch.distributed.init_process_group("nccl", device_id=device)
+        return rank, world, device, torch.distributed.group.WORLD
+    device = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(device)
+    return 0, 1, device, None
+
+
+def plan_num_blocks(args: EngineArgs, cfg: ModelConfig, tp_size: int, num_layers: int, max_model_len: int,
+                    elem_size: int, device) -> int:
+    """KV pages to allocate: what max_num_seqs sequences of max_model_len tokens
+    can ever use, capped by the memory budget (gpu_memory_utilization of the card
+    minus what is already resident and an activation reserve).  The harness's
+    default utilisation is 0.0 (benchmark-vllm/models.py:8): then only the cap by
+    free memory applies."""
+    per_block = 2 * num_layers * (cfg.num_key_value_heads // tp_size) * BLOCK_SIZE * cfg.head_dim * elem_size
+    blocks_per_seq = (max_model_len + BLOCK_SIZE - 1) // BLOCK_SIZE
+    want = args.max_num_seqs * blocks_per_seq + 1
+    free, total = torch.cuda.mem_get_info(device)
+    reserve = 6 << 30
+    util = args.gpu_memory_utilization if args.gpu_memory_utilization and args.gpu_memory_utilization > 0 else 0.9
+    budget = min(free - reserve, int(total * util) - (total - free) - reserve)
+    fit = max(int(budget // per_block), 0)
+    n = min(want, fit)
+    if n < blocks_per_seq:
+        raise RuntimeError(f"not enough GPU memory for the KV cache: {fit} pages fit, one sequence of "
+                           f"max_model_len {max_model_len} needs {blocks_per_seq}")
+    return n
+
+
+def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_config: Optional[ModelConfig] = None,
+                 decode_splits: Optional[int] = None) -> LLMEngine:
+    args.validate()
+    rank, world, device, group = init_distributed(args.tensor_parallel_size)
+    cfg = model_config or ModelConfig.from_pretrained(args.model)
+    dtype = TORCH_DTYPE[args.resolved_dtype()]
+    if (args.dtype or "").lower() in ("float32", "float"):
+        log.warning("--dtype float32 requested: the gfx950 kernels compute in 16 bits, serving in bfloat16")
+    if args.block_size != BLOCK_SIZE:
+        log.warning("--block-size %d requested: this engine always uses %d-token KV pages",
+                    args.block_size, BLOCK_SIZE)
+    max_model_len = args.max_model_len or min(cfg.max_position_embeddings, 8192)
+    nl = args.num_layers_override
+    kw = dict(tp_rank=rank, tp_size=world if args.tensor_parallel_size > 1 else 1, num_layers=nl)
+    if state_dict is not None:
+        weights = W.from_state_dict(cfg, state_dict, dtype, device, **kw)
+    elif args.load_format != "dummy" and W.has_checkpoint(args.model):
+        weights = W.from_safetensors(cfg, args.model, dtype, device, **kw)
+    else:
+        if args.load_format != "dummy":
+            log.warning("no *.safetensors under %r: using seeded synthetic weights (nothing is downloaded)",
+                        args.model)
+        weights = W.synthetic(cfg, dtype, device, seed=args.seed, **kw)
+    tp = kw["tp_size"]
+    num_blocks = plan_num_blocks(args, cfg, tp, len(weights.layers), max_model_len,
+                                 torch.empty(0, dtype=dtype).element_size(), device)
+    runner = ModelRunner(cfg, weights, dtype, device, num_blocks, args.max_num_seqs, max_model_len,
+                         tp_rank=rank, tp_size=tp, tp_group=group, use_graphs=not args.enforce_eager,
+                         decode_splits=decode_splits)
+    eos = cfg.eos_token_id
+    eos = [] if eos is None else (list(eos) if isinstance(eos, (list, tuple)) else [eos])
+    return LLMEngine(runner, args.max_num_seqs, max(args.max_num_batched_tokens, 1), max_model_len, eos)
+
+
+class LLM:
+    """Offline batch generation over token-id prompts."""
+
+    def __init__(self, engine: LLMEngine):
+        self.engine = engine
+
+    @classmethod
+    def from_engine_args(cls, args: EngineArgs, **kw) -> "LLM":
+        return cls(build_engine(args, **kw))
+
+    def generate(self, prompt_token_ids: List[List[int]], params: SamplingParams) -> List[List[int]]:
+        eng = self.engine
+        out = {}
+        for i, p in enumerate(prompt_token_ids):
+            eng.add_request(f"offline-{i}", p, params)
+            out[f"offline-{i}"] = []
+        while eng.has_unfinished():
+            for o in eng.step():
+                out[o.request_id].extend(o.new_token_ids)
+        return [out[f"offline-{i}"] for i in range(len(prompt_token_ids))]

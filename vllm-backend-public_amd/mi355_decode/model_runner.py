@@ -1,0 +1,278 @@
+"""One model step on one GPU: embed -> L x [norm, qkv, rope+kv-store, paged
+attention, o-proj (+all-reduce under TP), norm, gate_up, SwiGLU, down] -> norm ->
+lm_head -> greedy token.
+
+The hot operators go through the C ABI (mi355_decode.ops -> libmi355_decode.so);
+the linear layers are plain GEMMs on the same stream.  PyTorch only owns memory,
+streams and the process group.  The decode step works on statically allocated
+buffers and is captured once per batch-size bucket into a HIP graph (a decode
+step is ~300 short kernels; replay removes the per-launch host cost); prefill
+runs eagerly.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import ops
+from ._lib import BLOCK_SIZE
+from .config import ModelConfig
+from .weights import ModelWeights
+
+
+def build_cos_sin_table(cfg: ModelConfig, max_pos: int, dtype: torch.dtype, device) -> torch.Tensor:
+    """[max_pos, head_dim] = cos | sin halves, computed in fp32 and rounded to the
+    model dtype (the table a 16-bit model rotates with)."""
+    d = cfg.head_dim
+    inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.int64).float() / d))
+    sc = cfg.rope_scaling
+    if sc is not None:  # "llama3" frequency-dependent scaling
+        factor, low, high = sc["factor"], sc["low_freq_factor"], sc["high_freq_factor"]
+        old = sc["original_max_position_embeddings"]
+        wavelen = 2 * math.pi / inv_freq
+        scaled = torch.where(wavelen > old / low, inv_freq / factor, inv_freq)
+        smooth = (old / wavelen - low) / (high - low)
+        smoothed = (1 - smooth) * scaled / factor + smooth * scaled
+        mid = (wavelen >= old / high) & (wavelen <= old / low)
+        inv_freq = torch.where(mid, smoothed, scaled)
+    freqs = torch.outer(torch.arange(max_pos, dtype=torch.float32), inv_freq.float())
+    return torch.cat([freqs.cos(), freqs.sin()], dim=1).to(dtype).contiguous().to(device)
+
+
+def batch_buckets(max_num_seqs: int):
+    """Padded batch sizes a decode graph is captured for."""
+    sizes = [1, 2, 4] + list(range(8, 257, 8)) + list(range(288, 1025, 32))
+    out = [s for s in sizes if s < max_num_seqs]
+    out.append(max_num_seqs)
+    return out
+
+
+class ModelRunner:
+    def __init__(self, cfg: ModelConfig, weights: ModelWeights, dtype: torch.dtype, device,
+                 num_blocks: int, max_num_seqs: int, max_model_len: int, tp_rank: int = 0,
+                 tp_size: int = 1, tp_group=None, use_graphs: bool = True,
+                 decode_splits: Optional[int] = None):
+        self.cfg, self.w, self.dtype, self.device = cfg, weights, dtype, torch.device(device)
+        self.tp_rank, self.tp_size, self.tp_group = tp_rank, tp_size, tp_group
+        self.nh = cfg.num_attention_heads // tp_size
+        self.nkv = cfg.num_key_value_heads // tp_size
+        self.d = cfg.head_dim
+        self.H, self.F, self.V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+        self.L = len(weights.layers)
+        self.qw = (self.nh + 2 * self.nkv) * self.d
+        self.scale = self.d ** -0.5
+        self.eps = cfg.rms_norm_eps
+        self.num_blocks = int(num_blocks)
+        self.max_num_seqs = int(max_num_seqs)
+        self.max_model_len = int(max_model_len)
+        self.max_blocks = (self.max_model_len + BLOCK_SIZE - 1) // BLOCK_SIZE
+        self.use_graphs = use_graphs
+        self.decode_splits = decode_splits
+
+        dev = self.device
+        self.cos_sin = build_cos_sin_table(cfg, self.max_model_len, dtype, dev)
+        # paged KV cache, zero-filled so that every slot always holds finite values
+        self.k_cache = [torch.zeros(self.num_blocks, self.nkv, BLOCK_SIZE, self.d, dtype=dtype, device=dev)
+                        for _ in range(self.L)]
+        self.v_cache = [torch.zeros(self.num_blocks, self.nkv, self.d, BLOCK_SIZE, dtype=dtype, device=dev)
+                        for _ in range(self.L)]
+
+        B = self.max_num_seqs
+        i64 = dict(dtype=torch.int64, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        f = dict(dtype=dtype, device=dev)
+        # step inputs (static addresses: the decode graphs read them).  Packed so the
+        # engine refreshes them with two host-to-device copies per step:
+        #   in64 = ids | positions | slots            (3 * B int64)
+        #   in32 = context_lens | block_tables        (B + B * max_blocks int32)
+        self.in64 = torch.zeros(3 * B, **i64)
+        self.in32 = torch.zeros(B + B * self.max_blocks, **i32)
+        self.ids, self.positions, self.slots = self.in64[:B], self.in64[B:2 * B], self.in64[2 * B:]
+        self.slots.fill_(-1)
+        self.ctx = self.in32[:B]
+        self.block_tables = self.in32[B:].view(B, self.max_blocks)
+        # activations
+        self.resid = torch.zeros(B, self.H, **f)
+        self.x = torch.zeros(B, self.H, **f)
+        self.qkv = torch.zeros(B, self.qw, **f)
+        self.attn = torch.zeros(B, self.nh * self.d, **f)
+        self.o = torch.zeros(B, self.H, **f)
+        self.gu = torch.zeros(B, 2 * self.F, **f)
+        self.act = torch.zeros(B, self.F, **f)
+        self.dn = torch.zeros(B, self.H, **f)
+        self.logits = torch.zeros(B, self.V, **f)
+        self.next_ids = torch.zeros(B, **i64)
+        self._max_splits = 16
+        self.attn_ws = torch.empty(max(ops.decode_workspace_bytes(B, self.nh, self.d, self._max_splits), 16),
+                                   dtype=torch.uint8, device=dev)
+        self.graphs = {}
+        self.buckets = batch_buckets(B)
+        # pinned host staging for the packed inputs and the sampled tokens
+        self.h64 = torch.zeros(3 * B, dtype=torch.int64).pin_memory()
+        self.h32 = torch.zeros(B + B * self.max_blocks, dtype=torch.int32).pin_memory()
+        self.h_next = torch.zeros(B, dtype=torch.int64).pin_memory()
+
+    # ------------------------------------------------------------------ #
+    def kv_cache_bytes_per_block(self) -> int:
+        return 2 * self.L * self.nkv * BLOCK_SIZE * self.d * self.k_cache[0].element_size()
+
+    def _splits_for(self, batch: int) -> int:
+        if self.decode_splits:
+            return int(self.decode_splits)
+        wgs = batch * self.nkv
+        want = max(1, 512 // max(wgs, 1))
+        by_len = max(1, self.max_model_len // 256)      # keep >= 2 wave-steps per workgroup
+        return max(1, min(want, by_len, self._max_splits))
+
+    def _allreduce(self, t: torch.Tensor) -> None:
+        if self.tp_size > 1:
+            torch.distributed.all_reduce(t, group=self.tp_group)
+
+    def _layers(self, n: int, resid, x, qkv, attn, o, gu, act, dn, attend) -> torch.Tensor:
+        """Runs all decoder layers over n packed tokens held in `resid`.  Returns the
+        buffer holding the last MLP output (to be added to `resid` by the final norm)."""
+        w = self.w
+        for i, lw in enumerate(w.layers):
+            if i == 0:
+                ops.rms_norm(resid, lw.input_norm, self.eps, out=x)
+            else:
+                ops.fused_add_rms_norm(dn, resid, lw.input_norm, self.eps, out=x)
+            if lw.qkv_b is None:
+                torch.mm(x, lw.qkv_w.t(), out=qkv)
+            else:
+                torch.addmm(lw.qkv_b, x, lw.qkv_w.t(), out=qkv)
+            attend(i, qkv, attn)
+            torch.mm(attn, lw.o_w.t(), out=o)
+            self._allreduce(o)
+            ops.fused_add_rms_norm(o, resid, lw.post_norm, self.eps, out=x)
+            torch.mm(x, lw.gate_up_w.t(), out=gu)
+            ops.silu_and_mul(gu, out=act)
+            torch.mm(act, lw.down_w.t(), out=dn)
+        return dn
+
+    # ------------------------------------------------------------------ #
+    # decode: one token per sequence, static buffers, HIP-graph replay
+    # ------------------------------------------------------------------ #
+    def _decode_body(self, b: int) -> None:
+        ids, pos, slots, ctx, bt = self.ids[:b], self.positions[:b], self.slots[:b], self.ctx[:b], self.block_tables[:b]
+        resid, x, qkv, attn = self.resid[:b], self.x[:b], self.qkv[:b], self.attn[:b]
+        o, gu, act, dn = self.o[:b], self.gu[:b], self.act[:b], self.dn[:b]
+        splits = self._splits_for(b)
+        torch.index_select(self.w.embed, 0, ids, out=resid)
+
+        def attend(i, qkv_, attn_):
+            ops.rope_kv_write(qkv_, pos, self.cos_sin, slots, self.k_cache[i], self.v_cache[i],
+                              self.nh, self.nkv, self.d)
+            ops.paged_attn_decode(qkv_[:, : self.nh * self.d], self.k_cache[i], self.v_cache[i], bt, ctx,
+                                  self.nh, self.nkv, self.d, self.scale, num_splits=splits,
+                                  workspace=self.attn_ws, out=attn_)
+
+        last = self._layers(b, resid, x, qkv, attn, o, gu, act, dn, attend)
+        ops.fused_add_rms_norm(last, resid, self.w.final_norm, self.eps, out=x)
+        torch.mm(x, self.w.lm_head.t(), out=self.logits[:b])
+        ops.argmax(self.logits[:b], out=self.next_ids[:b])
+
+    def bucket_for(self, batch: int) -> int:
+        for s in self.buckets:
+            if s >= batch:
+                return s
+        raise ValueError(f"batch {batch} exceeds max_num_seqs {self.max_num_seqs}")
+
+    def capture(self, bucket: int) -> None:
+        """Warm up and capture the decode step for one padded batch size."""
+        if bucket in self.graphs:
+            return
+        # neutral inputs: padded rows store nothing and attend to nothing
+        self.slots[:bucket].fill_(-1)
+        self.ctx[:bucket].zero_()
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._decode_body(bucket)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._decode_body(bucket)
+        self.graphs[bucket] = g
+
+    def decode(self, batch: int) -> torch.Tensor:
+        """Runs one decode step over the first `batch` rows of the static input
+        buffers (ids, positions, slots, ctx, block_tables must be filled; rows
+        beyond `batch` up to the bucket size must be neutral: slot -1, ctx 0).
+        Returns a view of the sampled (greedy) token ids, on the device."""
+        if not self.use_graphs:
+            self._decode_body(batch)
+            return self.next_ids[:batch]
+        bucket = self.bucket_for(batch)
+        if bucket not in self.graphs:
+            self.capture(bucket)
+        self.graphs[bucket].replay()
+        return self.next_ids[:batch]
+
+    def host_inputs(self):
+        """numpy views of the pinned staging buffers, laid out like in64 / in32."""
+        return self.h64.numpy(), self.h32.numpy()
+
+    def run_decode(self, batch: int):
+        """Host-facing decode step: ships the staged inputs, replays the step and
+        returns the sampled token ids as a Python list (one stream sync)."""
+        self.in64.copy_(self.h64, non_blocking=True)
+        self.in32.copy_(self.h32, non_blocking=True)
+        nxt = self.decode(batch)
+        self.h_next[:batch].copy_(nxt, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return self.h_next[:batch].tolist()
+
+    def run_prefill(self, token_ids, positions, slot_mapping, block_tables, cu_seqlens, context_lens,
+                    max_q_len: int):
+        """Host-facing prefill step over numpy inputs; returns next-token ids (list)."""
+        dev = self.device
+
+        def t(a, dt):
+            return torch.from_numpy(a).to(dev, dtype=dt, non_blocking=True)
+
+        nxt, _ = self.prefill(t(token_ids, torch.int64), t(positions, torch.int64), t(slot_mapping, torch.int64),
+                              t(block_tables, torch.int32), t(cu_seqlens, torch.int32),
+                              t(context_lens, torch.int32), int(max_q_len), want_logits=False)
+        return nxt.cpu().tolist()
+
+    # ------------------------------------------------------------------ #
+    # prefill: packed variable-length prompts (or prompt chunks), eager
+    # ------------------------------------------------------------------ #
+    def prefill(self, token_ids: torch.Tensor, positions: torch.Tensor, slot_mapping: torch.Tensor,
+                block_tables: torch.Tensor, cu_seqlens: torch.Tensor, context_lens: torch.Tensor,
+                max_q_len: int, want_logits: bool = True):
+        """token_ids/positions/slot_mapping: int64 [T] on the device; block_tables
+        int32 [S, max_blocks]; cu_seqlens int32 [S+1]; context_lens int32 [S].
+        Returns (greedy next token per sequence [S], logits [S, V] or None)."""
+        T = token_ids.numel()
+        f = dict(dtype=self.dtype, device=self.device)
+        resid = torch.index_select(self.w.embed, 0, token_ids)
+        x = torch.empty(T, self.H, **f)
+        qkv = torch.empty(T, self.qw, **f)
+        attn = torch.empty(T, self.nh * self.d, **f)
+        o = torch.empty(T, self.H, **f)
+        gu = torch.empty(T, 2 * self.F, **f)
+        act = torch.empty(T, self.F, **f)
+        dn = torch.empty(T, self.H, **f)
+
+        def attend(i, qkv_, attn_):
+            ops.rope_kv_write(qkv_, positions, self.cos_sin, slot_mapping, self.k_cache[i], self.v_cache[i],
+                              self.nh, self.nkv, self.d)
+            ops.paged_attn_prefill(qkv_[:, : self.nh * self.d], self.k_cache[i], self.v_cache[i], block_tables,
+                                   cu_seqlens, context_lens, max_q_len, self.nh, self.nkv, self.d, self.scale,
+                                   out=attn_)
+
+        last = self._layers(T, resid, x, qkv, attn, o, gu, act, dn, attend)
+        rows = (cu_seqlens[1:] - 1).to(torch.int64)
+        last_sel = last.index_select(0, rows)
+        resid_sel = resid.index_select(0, rows)
+        xs = torch.empty_like(last_sel)
+        ops.fused_add_rms_norm(last_sel, resid_sel, self.w.final_norm, self.eps, out=xs)
+        logits = torch.mm(xs, self.w.lm_head.t())
+        nxt = ops.argmax(logits)
+        return nxt, (logits if want_logits else None)

@@ -1,0 +1,164 @@
+"""Model weights in the layout the kernels and GEMMs consume.
+
+Per layer the q/k/v projections are concatenated into one [ (nh + 2*nkv) * d, H ]
+matrix and gate/up into one [2F, H] matrix, all row-major [out, in] in the model
+dtype.  Under tensor parallelism (one process per GPU) rank r keeps query heads
+[r*nh/P, (r+1)*nh/P), the matching kv heads, the matching COLUMNS of o_proj
+(row-parallel: partial sums are all-reduced), and full copies of the MLP, the
+embeddings and lm_head.
+
+Sources: a local HF directory with *.safetensors (the harness serves models
+from a local path, benchmark-mlflow/vllm_processor.py:29), an in-memory state
+dict (tests), or seeded synthetic weights of the right shapes
+(``--load-format dummy``; also the fallback when the directory holds no weight
+files, because nothing can be downloaded).
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+from dataclasses import dataclass, field
+from typing import Callable, Optional
+
+import torch
+
+from .config import ModelConfig
+
+
+@dataclass
+class LayerWeights:
+    qkv_w: torch.Tensor
+    qkv_b: Optional[torch.Tensor]
+    o_w: torch.Tensor
+    gate_up_w: torch.Tensor
+    down_w: torch.Tensor
+    input_norm: torch.Tensor
+    post_norm: torch.Tensor
+
+
+@dataclass
+class ModelWeights:
+    embed: torch.Tensor
+    layers: list = field(default_factory=list)
+    final_norm: torch.Tensor = None
+    lm_head: torch.Tensor = None
+    synthetic: bool = False
+
+    def nbytes(self) -> int:
+        total = self.embed.numel() * self.embed.element_size()
+        if self.lm_head.data_ptr() != self.embed.data_ptr():
+            total += self.lm_head.numel() * self.lm_head.element_size()
+        total += self.final_norm.numel() * self.final_norm.element_size()
+        for lw in self.layers:
+            for t in (lw.qkv_w, lw.qkv_b, lw.o_w, lw.gate_up_w, lw.down_w, lw.input_norm, lw.post_norm):
+                if t is not None:
+                    total += t.numel() * t.element_size()
+        return total
+
+
+def _shard_heads(cfg: ModelConfig, tp_rank: int, tp_size: int):
+    nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    if nh % tp_size or nkv % tp_size:
+        raise ValueError(f"tensor_parallel_size {tp_size} must divide num_attention_heads {nh} and "
+                         f"num_key_value_heads {nkv}")
+    nh_l, nkv_l = nh // tp_size, nkv // tp_size
+    return nh_l, nkv_l, slice(tp_rank * nh_l * cfg.head_dim, (tp_rank + 1) * nh_l * cfg.head_dim), \
+        slice(tp_rank * nkv_l * cfg.head_dim, (tp_rank + 1) * nkv_l * cfg.head_dim)
+
+
+def from_getter(cfg: ModelConfig, get: Callable[[str], torch.Tensor], dtype: torch.dtype, device,
+                tp_rank: int = 0, tp_size: int = 1, num_layers: Optional[int] = None) -> ModelWeights:
+    """``get(name)`` returns the full (unsharded) CPU tensor of an HF parameter."""
+    _, _, qs, ks = _shard_heads(cfg, tp_rank, tp_size)
+
+    def put(t: torch.Tensor) -> torch.Tensor:
+        return t.to(dtype).contiguous().to(device)
+
+    L = num_layers if num_layers is not None else cfg.num_hidden_layers
+    w = ModelWeights(embed=put(get("model.embed_tokens.weight")))
+    for i in range(L):
+        p = f"model.layers.{i}."
+        q, k, v = (get(p + f"self_attn.{n}_proj.weight") for n in "qkv")
+        qkv_w = torch.cat([q[qs], k[ks], v[ks]], dim=0)
+        qkv_b = None
+        if cfg.attention_bias:
+            qb, kb, vb = (get(p + f"self_attn.{n}_proj.bias") for n in "qkv")
+            qkv_b = put(torch.cat([qb[qs], kb[ks], vb[ks]], dim=0))
+        o = get(p + "self_attn.o_proj.weight")[:, qs]
+        gu = torch.cat([get(p + "mlp.gate_proj.weight"), get(p + "mlp.up_proj.weight")], dim=0)
+        w.layers.append(LayerWeights(
+            qkv_w=put(qkv_w), qkv_b=qkv_b, o_w=put(o), gate_up_w=put(gu),
+            down_w=put(get(p + "mlp.down_proj.weight")),
+            input_norm=put(get(p + "input_layernorm.weight")),
+            post_norm=put(get(p + "post_attention_layernorm.weight"))))
+    w.final_norm = put(get("model.norm.weight"))
+    w.lm_head = w.embed if cfg.tie_word_embeddings else put(get("lm_head.weight"))
+    return w
+
+
+def from_state_dict(cfg, state: dict, dtype, device, **kw) -> ModelWeights:
+    def get(name):
+        t = state[name]
+        return t if isinstance(t, torch.Tensor) else torch.from_numpy(t)
+    return from_getter(cfg, get, dtype, device, **kw)
+
+
+def has_checkpoint(model_dir: str) -> bool:
+    return os.path.isdir(model_dir) and bool(glob.glob(os.path.join(model_dir, "*.safetensors")))
+
+
+def from_safetensors(cfg, model_dir: str, dtype, device, **kw) -> ModelWeights:
+    from safetensors import safe_open
+
+    index = os.path.join(model_dir, "model.safetensors.index.json")
+    files = sorted(glob.glob(os.path.join(model_dir, "*.safetensors")))
+    where = {}
+    if os.path.isfile(index):
+        with open(index) as f:
+            where = {k: os.path.join(model_dir, v) for k, v in json.load(f)["weight_map"].items()}
+    handles = {}
+
+    def get(name):
+        path = where.get(name)
+        if path is None:
+            for fpath in files:
+                h = handles.setdefault(fpath, safe_open(fpath, framework="pt", device="cpu"))
+                if name in h.keys():
+                    path = fpath
+                    break
+            else:
+                raise KeyError(f"{name} not found in {model_dir}")
+        h = handles.setdefault(path, safe_open(path, framework="pt", device="cpu"))
+        return h.get_tensor(name)
+
+    return from_getter(cfg, get, dtype, device, **kw)
+
+
+def synthetic(cfg: ModelConfig, dtype, device, seed: int = 0, tp_rank: int = 0, tp_size: int = 1,
+              num_layers: Optional[int] = None, std: float = 0.02) -> ModelWeights:
+    """Seeded N(0, std^2) matrices of the real shapes, generated on the device
+    (an 8B model is 15 GB: too slow to draw on the host).  Every rank draws the
+    replicated tensors from the same stream so they are bit-identical across ranks."""
+    nh_l, nkv_l, _, _ = _shard_heads(cfg, tp_rank, tp_size)
+    H, F, V, d = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.head_dim
+    shared = torch.Generator(device=device).manual_seed(seed)
+    local = torch.Generator(device=device).manual_seed(seed * 1000003 + 17 + tp_rank)
+
+    def mat(gen, *shape):
+        return torch.empty(shape, dtype=dtype, device=device).normal_(0.0, std, generator=gen)
+
+    L = num_layers if num_layers is not None else cfg.num_hidden_layers
+    w = ModelWeights(embed=mat(shared, V, H), synthetic=True)
+    for _ in range(L):
+        w.layers.append(LayerWeights(
+            qkv_w=mat(local, (nh_l + 2 * nkv_l) * d, H),
+            qkv_b=mat(local, (nh_l + 2 * nkv_l) * d) if cfg.attention_bias else None,
+            o_w=mat(local, H, nh_l * d),
+            gate_up_w=mat(shared, 2 * F, H),
+            down_w=mat(shared, H, F),
+            input_norm=torch.ones(H, dtype=dtype, device=device),
+            post_norm=torch.ones(H, dtype=dtype, device=device)))
+    w.final_norm = torch.ones(H, dtype=dtype, device=device)
+    w.lm_head = w.embed if cfg.tie_word_embeddings else mat(shared, V, H)
+    return w
