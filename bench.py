@@ -1,0 +1,333 @@
+#!/usr/bin/env python3
+"""Decode-throughput benchmark of the MI355X engine on BASELINE.json's headline
+workload: Llama-3-8B geometry, bf16, batch 32 per GPU, 128 tokens in / 128 out,
+synthetic weights and token-id prompts.
+
+    python bench.py --gpus 1 --steps 127 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 4 --steps 127 --warmup 10
+
+A "step" is one engine decode step: every running sequence advances one token
+(scheduler bookkeeping, two small host-to-device copies, one HIP-graph replay of
+the whole model step including greedy sampling, token ids back to the host).
+The timed region starts with all prompts prefilled (K/V resident in HBM) and
+covers exactly K steps; contexts grow from prompt_len+1 as in a real generation,
+and a fresh batch is prefilled (untimed) whenever the sequences reach their
+output length.  With N > 1 GPUs the model runs tensor-parallel over attention
+heads (one process per GPU, RCCL all-reduce on the attention output projection)
+and the batch grows to 32*N sequences (weak scaling, BASELINE.json configs[2]).
+
+Rank 0 prints ONE JSON line: the contract fields plus
+  ttft_ms_p50   time to first token of the batch's prefill (prompt_len*batch tokens)
+  roofline      the dominant kernel of the step (the gate/up projection GEMM):
+                algorithmic bytes / average launch time measured here with HIP events
+  step_roofline the whole decode step against the HBM roofline (bytes per step from
+                the model geometry and mean context / measured step time)
+  kernels       the hand-written HIP kernels, each timed with HIP events
+  cpu_baseline  the numpy oracle timed on this host on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "vllm-backend-public_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=127)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--model", default="llama-3-8b")
+    ap.add_argument("--batch-per-gpu", type=int, default=32)
+    ap.add_argument("--prompt-len", type=int, default=128)
+    ap.add_argument("--gen-len", type=int, default=128)
+    ap.add_argument("--dtype", default="bfloat16")
+    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is marked invalid)")
+    ap.add_argument("--decode-splits", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="debug only: no HIP graphs")
+    return ap.parse_args()
+
+
+def model_bytes(cfg, tp, batch, mean_ctx, elem=2):
+    """Algorithmic HBM bytes of one decode step per GPU: every weight once
+    (attention projections sharded over tp, MLP and lm_head replicated), the K/V
+    pages of the mean context, the new K/V rows, and the logits."""
+    H, F, V, L, d = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.num_hidden_layers, cfg.head_dim
+    nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    attn_w = ((nh + 2 * nkv) * d * H + nh * d * H) // tp
+    mlp_w = 3 * F * H
+    norms = 2 * H
+    w = L * (attn_w + mlp_w + norms) + V * H + H
+    kv_tok = 2 * (nkv // tp) * d * elem * L
+    return w * elem + batch * mean_ctx * kv_tok + batch * kv_tok + batch * V * elem, w * elem
+
+
+def make_prompts(vocab, batch, plen, seed):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    lo, hi = min(1000, vocab // 4), max(vocab - 1000, vocab // 2)
+    return torch.randint(lo, hi, (batch, plen), generator=g).tolist()
+
+
+def time_kernels(engine, batch, ctx_len):
+    """Average launch time of each kernel of the decode step, with HIP events on
+    the launch stream.  Launches walk over the layers so that consecutive launches
+    touch different weights / KV pages (nothing is served from the Infinity Cache
+    that a real step would have to fetch from HBM)."""
+    import torch
+    from mi355_decode import ops
+    r = engine.runner
+    b = batch
+    L = r.L
+    reps = max(1, 64 // L)
+    out = {}
+
+    def timed(fn, bytes_per_launch):
+        for i in range(min(L, 4)):
+            fn(i)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            for i in range(L):
+                fn(i)
+        e.record()
+        e.synchronize()
+        us = s.elapsed_time(e) * 1000.0 / (reps * L)
+        return {"us": round(us, 2), "bytes": int(bytes_per_launch),
+                "gbs": round(bytes_per_launch / us / 1e3, 1), "frac": round(bytes_per_launch / us / 1e3 / HBM_PEAK_GBS, 4)}
+
+    es = 2
+    x, qkv, attn, o, gu, act, dn, resid = r.x[:b], r.qkv[:b], r.attn[:b], r.o[:b], r.gu[:b], r.act[:b], r.dn[:b], r.resid[:b]
+    W = r.w.layers
+    gemm = lambda m, n, k: (n * k + m * k + m * n) * es   # noqa: E731
+    out["gemm_gate_up"] = timed(lambda i: torch.mm(x, W[i].gate_up_w.t(), out=gu), gemm(b, 2 * r.F, r.H))
+    out["gemm_down"] = timed(lambda i: torch.mm(act, W[i].down_w.t(), out=dn), gemm(b, r.H, r.F))
+    out["gemm_qkv"] = timed(lambda i: torch.mm(x, W[i].qkv_w.t(), out=qkv), gemm(b, r.qw, r.H))
+    out["gemm_o"] = timed(lambda i: torch.mm(attn, W[i].o_w.t(), out=o), gemm(b, r.H, r.nh * r.d))
+    lm = r.w.lm_head
+    out["gemm_lm_head"] = timed(lambda i: torch.mm(x, lm.t(), out=r.logits[:b]), gemm(b, r.V, r.H))
+
+    # attention over the live cache, at the context lengths of the last timed step
+    n64, n32 = r.host_inputs()
+    r.in64.copy_(r.h64)
+    r.in32.copy_(r.h32)
+    splits = r._splits_for(b)
+    ctx_tokens = int(n32[:b].sum())
+    kv_bytes = ctx_tokens * 2 * r.nkv * r.d * es + 2 * b * r.nh * r.d * es
+    out["paged_attn_decode"] = timed(
+        lambda i: ops.paged_attn_decode(qkv[:, : r.nh * r.d], r.k_cache[i], r.v_cache[i], r.block_tables[:b], r.ctx[:b],
+                                        r.nh, r.nkv, r.d, r.scale, num_splits=splits, workspace=r.attn_ws, out=attn),
+        kv_bytes)
+    out["paged_attn_decode"]["splits"] = splits
+    out["rope_kv_write"] = timed(
+        lambda i: ops.rope_kv_write(qkv, r.positions[:b], r.cos_sin, r.slots[:b], r.k_cache[i], r.v_cache[i], r.nh, r.nkv, r.d),
+        b * ((r.nh + r.nkv) * r.d * 2 + r.nkv * r.d + 2 * r.nkv * r.d) * es)
+    out["fused_add_rms_norm"] = timed(lambda i: ops.fused_add_rms_norm(o, resid, W[i].post_norm, r.eps, out=x), 5 * b * r.H * es)
+    out["silu_and_mul"] = timed(lambda i: ops.silu_and_mul(gu, out=act), 3 * b * r.F * es)
+    out["argmax"] = timed(lambda i: ops.argmax(r.logits[:b], out=r.next_ids[:b]), b * r.V * es)
+    return out
+
+
+def cpu_baseline(cfg, batch, ctx_len, sample_layers=2, steps=2):
+    """The numpy oracle (oracle/model_ref.py) timed on this host: one decode step of
+    `batch` sequences at context `ctx_len` through `sample_layers` real-shape layers
+    plus the lm_head, scaled to the model's layer count."""
+    import numpy as np
+    from oracle import model_ref as M
+    from oracle.ops_ref import round_to
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    H, F, V, d = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.head_dim
+    nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    rng = np.random.Generator(np.random.PCG64(0))
+
+    def mat(*shape):
+        return round_to(rng.standard_normal(shape, dtype=np.float32) * np.float32(0.02), "bfloat16")
+
+    w = {"model.embed_tokens.weight": mat(V, H), "lm_head.weight": mat(V, H), "model.norm.weight": np.ones(H, np.float32)}
+    for i in range(sample_layers):
+        p = f"model.layers.{i}."
+        w[p + "self_attn.q_proj.weight"], w[p + "self_attn.k_proj.weight"] = mat(nh * d, H), mat(nkv * d, H)
+        w[p + "self_attn.v_proj.weight"], w[p + "self_attn.o_proj.weight"] = mat(nkv * d, H), mat(H, nh * d)
+        w[p + "mlp.gate_proj.weight"], w[p + "mlp.up_proj.weight"], w[p + "mlp.down_proj.weight"] = mat(F, H), mat(F, H), mat(H, F)
+        w[p + "input_layernorm.weight"] = w[p + "post_attention_layernorm.weight"] = np.ones(H, np.float32)
+    rc = M.RefConfig(vocab_size=V, hidden_size=H, intermediate_size=F, num_hidden_layers=sample_layers,
+                     num_attention_heads=nh, num_key_value_heads=nkv, head_dim=d, rope_theta=cfg.rope_theta,
+                     rms_norm_eps=cfg.rms_norm_eps, max_position_embeddings=ctx_len + steps + 1)
+    blocks_per_seq = (ctx_len + steps + 16) // 16
+    model = M.RefModel(rc, w, "bfloat16", num_blocks=batch * blocks_per_seq, layers=sample_layers)
+    for kc, vc in zip(model.k_cache, model.v_cache):
+        kc[:] = mat(*kc.shape)
+        vc[:] = mat(*vc.shape)
+    bt = np.arange(batch * blocks_per_seq, dtype=np.int32).reshape(batch, blocks_per_seq)
+    ids = rng.integers(0, V, batch)
+
+    def one_step(k, layers_only):
+        pos = np.full(batch, ctx_len - 1 + k, dtype=np.int64)
+        slots = bt[np.arange(batch), pos // 16].astype(np.int64) * 16 + pos % 16
+        t0 = time.perf_counter()
+        if layers_only:
+            saved = model.w["lm_head.weight"]
+            model.w["lm_head.weight"] = saved[:8]             # negligible lm_head: isolates the layer cost
+            model.forward(ids, pos, slots, bt, (pos + 1).astype(np.int32))
+            model.w["lm_head.weight"] = saved
+        else:
+            model.forward(ids, pos, slots, bt, (pos + 1).astype(np.int32))
+        return time.perf_counter() - t0
+
+    one_step(0, False)                                        # warm the BLAS threads
+    t_full = min(one_step(1 + k, False) for k in range(steps))
+    t_layers = min(one_step(1 + steps + k, True) for k in range(steps))
+    per_layer = t_layers / sample_layers
+    t_head = max(t_full - t_layers, 0.0)
+    step_s = per_layer * cfg.num_hidden_layers + t_head
+    return {"value": round(batch / step_s, 2), "unit": "tok/s", "cores": threads, "kind": "port",
+            "sample": (f"numpy oracle, {steps} decode steps of batch {batch} at context {ctx_len} through "
+                       f"{sample_layers} of {cfg.num_hidden_layers} real-shape layers + lm_head; per-layer time "
+                       f"{per_layer * 1e3:.0f} ms x {cfg.num_hidden_layers} + lm_head {t_head * 1e3:.0f} ms = "
+                       f"{step_s:.2f} s per step"),
+            "stock_vllm_cpu": "unavailable offline (vllm is not installed; nothing can be fetched)"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from mi355_decode.config import EngineArgs, ModelConfig
+    from mi355_decode.llm import build_engine
+    from mi355_decode.sampling_params import SamplingParams
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    tp = a.gpus
+    batch = a.batch_per_gpu * a.gpus
+    P, G = a.prompt_len, a.gen_len
+
+    cfg = ModelConfig.from_pretrained(a.model)
+    args = EngineArgs(model=a.model, dtype=a.dtype, max_num_seqs=batch, max_model_len=P + G,
+                      max_num_batched_tokens=max(8192, 1), tensor_parallel_size=tp, load_format="dummy",
+                      gpu_memory_utilization=0.9, enforce_eager=a.eager, num_layers_override=a.layers, seed=0)
+    engine = build_engine(args, model_config=cfg, decode_splits=a.decode_splits)
+    params = SamplingParams(max_tokens=G, temperature=0.0, ignore_eos=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    round_no = [0]
+
+    def start_batch():
+        """Admit and prefill a fresh batch; returns the prefill wall time (s)."""
+        prompts = make_prompts(cfg.vocab_size, batch, P, 1234 + round_no[0])
+        round_no[0] += 1
+        barrier()
+        t0 = time.perf_counter()
+        for i, p in enumerate(prompts):
+            engine.add_request(f"b{round_no[0]}-{i}", p, params)
+        while any(not s.output_ids for s in list(engine.sched.waiting) + engine.sched.running):
+            engine.step()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def drain():
+        for rid in list(engine.seqs):
+            engine.abort_request(rid)
+
+    # ---- warm-up: prefill shapes, graph capture, W decode steps
+    start_batch()
+    for _ in range(max(a.warmup, 1)):
+        engine.step()
+    drain()
+
+    # ---- TTFT: wall time from submitting the batch to its first tokens (one prefill pass)
+    ttfts = []
+    for _ in range(3):
+        ttfts.append(start_batch())
+        drain()
+    ttft_ms = sorted(ttfts)[len(ttfts) // 2] * 1e3
+
+    # ---- timed decode: exactly K steps, in segments of at most G-1 steps per batch
+    left, total_t, ctx_sum = a.steps, 0.0, 0
+    while left > 0:
+        start_batch()
+        seg = min(left, G - 1)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(seg):
+            engine.step()
+        barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=engine.device)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        total_t += float(dt.item())
+        ctx_sum += sum(P + 1 + k for k in range(seg))
+        left -= seg
+        if left > 0:
+            drain()
+    mean_ctx = ctx_sum / a.steps
+    ms_per_step = total_t / a.steps * 1e3
+    tok_s = batch * a.steps / total_t
+
+    step_bytes, w_bytes = model_bytes(cfg, tp, batch, mean_ctx)
+    if a.layers:
+        import copy
+        c2 = copy.copy(cfg)
+        c2.num_hidden_layers = a.layers
+        step_bytes, w_bytes = model_bytes(c2, tp, batch, mean_ctx)
+    step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
+
+    result = {
+        "metric": "decode_tok_s", "value": round(tok_s, 1), "unit": "tok/s", "n_gpus": a.gpus, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16" if a.dtype == "bfloat16" else a.dtype, "data": "synthetic",
+        "config": {"workload": f"{a.model} decode, batch {batch} ({a.batch_per_gpu}/GPU), {P}-in/{G}-out, greedy, "
+                               f"synthetic weights and token-id prompts; BASELINE.json configs[{1 if a.gpus == 1 else 2}]",
+                   "global_batch": batch, "prompt_len": P, "gen_len": G,
+                   "parallelism": f"tp{tp} (attention heads sharded, MLP+lm_head replicated)" if tp > 1 else "tp1",
+                   "mean_context": round(mean_ctx, 1), "hip_graphs": not a.eager},
+        "ttft_ms_p50": round(ttft_ms, 2),
+        "step_roofline": {"bound": "hbm", "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(step_gbs / HBM_PEAK_GBS, 4), "bytes_per_step": int(step_bytes),
+                          "weight_bytes": int(w_bytes), "roofline_tok_s": round(batch / (step_bytes / (HBM_PEAK_GBS * 1e9)), 1)},
+    }
+    if a.layers:
+        result["config"]["INVALID_reduced_layers"] = a.layers
+
+    if rank == 0 and not a.no_kernel_timing:
+        kern = time_kernels(engine, batch, int(mean_ctx))
+        result["kernels"] = kern
+        dom = kern["gemm_gate_up"]
+        result["roofline"] = {"bound": "hbm", "kernel": "gate/up projection GEMM (M=%d, N=%d, K=%d)" % (batch, 2 * cfg.intermediate_size, cfg.hidden_size),
+                              "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
+                              "traffic": None, "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"]}
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        if not a.no_cpu_baseline and a.gpus == 1:
+            result["cpu_baseline"] = cpu_baseline(cfg, a.batch_per_gpu, int(mean_ctx))
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,319 @@
+"""OpenAI-compatible completion server: the process the harness starts in place
+of the stock engine image.
+
+Routes the reference calls:
+  GET  /health          kubelet readiness/liveness probes (benchmark-vllm/vllm_templates.py:182-201,
+                        352-369) and the deployer's wait loop (benchmark-deployer/deployer_manager.py:1597-1608)
+  GET  /v1/models       benchmark-eval polls it until 200 before launching the evaluation job
+                        (benchmark-eval/main.py:102-110)
+  POST /v1/completions  the evaluation jobs' endpoint (benchmark-deployer/docs/deployment/post_run.md:46;
+                        env VLLM_MODEL_ENDPOINT, deployer_manager.py:2195-2199)
+
+The socket is bound before the weights are loaded: until the engine is ready
+/health and /v1/models answer 503 (a refused connection would make benchmark-eval
+drop the evaluation, benchmark-eval/main.py:105,131).  A fatal engine error turns
+/health into 500 and the process exits non-zero, so Kubernetes shows
+CrashLoopBackOff and the harness counts a failure (vllm_manager.py:921-936).
+
+    python -m mi355_decode.entrypoints.openai.api_server --model /data/local_models/X --port 8000 ...
+"""
+from __future__ import annotations
+
+import asyncio
+import json
+import logging
+import os
+import sys
+import time
+import uuid
+from typing import List, Optional, Union
+
+from ..cli_args import parse_args, sanitize_env
+
+log = logging.getLogger("mi355_decode")
+
+
+def _error(status: int, message: str, etype: str = "invalid_request_error"):
+    from fastapi.responses import JSONResponse
+    return JSONResponse(status_code=status,
+                        content={"error": {"message": message, "type": etype, "param": None, "code": status}})
+
+
+def normalise_prompts(prompt, tokenizer, vocab_size: int) -> List[List[int]]:
+    """prompt: str | [str] | [int] | [[int]]  ->  list of token-id prompts."""
+    if isinstance(prompt, str):
+        return [tokenizer.encode(prompt)]
+    if isinstance(prompt, list) and prompt:
+        if all(isinstance(p, str) for p in prompt):
+            return [tokenizer.encode(p) for p in prompt]
+        if all(isinstance(p, int) and not isinstance(p, bool) for p in prompt):
+            return [list(prompt)]
+        if all(isinstance(p, list) and p and all(isinstance(t, int) and not isinstance(t, bool) for t in p)
+               for p in prompt):
+            return [list(p) for p in prompt]
+    raise ValueError("prompt must be a string, a list of strings, a list of token ids or a list of token-id lists")
+
+
+def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int, max_model_len: int):
+    from fastapi import FastAPI, Request
+    from fastapi.responses import JSONResponse, Response, StreamingResponse
+
+    from ...sampling_params import SamplingParams
+    from ...tokenizer import IncrementalDetokenizer
+
+    app = FastAPI(title="mi355-decode", version="0.1.0")
+    created = int(time.time())
+
+    def not_ready():
+        if engine_thread.failed is not None:
+            return _error(500, f"engine failed: {engine_thread.failed!r}", "internal_error")
+        if not engine_thread.ready.is_set():
+            return _error(503, "engine is loading", "service_unavailable")
+        return None
+
+    @app.get("/health")
+    async def health():
+        bad = not_ready()
+        return bad if bad is not None else Response(status_code=200)
+
+    @app.get("/ping")
+    async def ping():
+        return await health()
+
+    @app.get("/version")
+    async def version():
+        from ... import __version__
+        return {"version": __version__, "engine": "mi355-decode"}
+
+    @app.get("/v1/models")
+    async def models():
+        bad = not_ready()
+        if bad is not None:
+            return bad
+        return {"object": "list", "data": [{"id": served_model_name, "object": "model", "created": created,
+                                            "owned_by": "mi355-decode", "root": served_model_name,
+                                            "parent": None, "max_model_len": max_model_len}]}
+
+    @app.get("/metrics")
+    async def metrics():
+        eng = engine_thread.engine
+        lines = [f"mi355_engine_steps_total {engine_thread.steps}",
+                 f"mi355_generation_tokens_total {engine_thread.tokens_out}",
+                 f"mi355_uptime_seconds {time.time() - engine_thread.started:.1f}"]
+        if eng is not None:
+            lines += [f"mi355_num_requests_running {len(eng.sched.running)}",
+                      f"mi355_num_requests_waiting {len(eng.sched.waiting)}",
+                      f"mi355_kv_blocks_free {eng.alloc.num_free}",
+                      f"mi355_kv_blocks_total {eng.alloc.num_blocks}"]
+        return Response("\n".join(lines) + "\n", media_type="text/plain")
+
+    @app.post("/v1/completions")
+    async def completions(request: Request):
+        bad = not_ready()
+        if bad is not None:
+            return bad
+        try:
+            body = await request.json()
+        except Exception:
+            return _error(400, "request body is not valid JSON")
+        if not isinstance(body, dict) or "prompt" not in body:
+            return _error(400, "missing field: prompt")
+        model = body.get("model") or served_model_name
+        if model != served_model_name:
+            return _error(404, f"The model `{model}` does not exist.", "NotFoundError")
+        try:
+            prompts = normalise_prompts(body["prompt"], tokenizer, vocab_size)
+            if body.get("n", 1) != 1 or body.get("best_of", 1) not in (None, 1):
+                raise ValueError("n > 1 / best_of > 1 are not supported")
+            if body.get("logprobs") not in (None, 0, False):
+                raise ValueError("logprobs is not supported yet")
+            stop = body.get("stop") or []
+            params = SamplingParams(
+                max_tokens=int(body.get("max_tokens", 16) if body.get("max_tokens") is not None else 16),
+                min_tokens=int(body.get("min_tokens", 0) or 0),
+                temperature=float(body.get("temperature", 1.0) if body.get("temperature") is not None else 1.0),
+                top_p=float(body.get("top_p", 1.0) if body.get("top_p") is not None else 1.0),
+                top_k=int(body.get("top_k", -1) if body.get("top_k") is not None else -1),
+                seed=body.get("seed"), stop=[stop] if isinstance(stop, str) else list(stop),
+                stop_token_ids=list(body.get("stop_token_ids") or []),
+                ignore_eos=bool(body.get("ignore_eos", False)))
+            for p in prompts:
+                if len(p) + 1 > max_model_len:
+                    raise ValueError(f"This model's maximum context length is {max_model_len} tokens; the prompt has "
+                                     f"{len(p)} tokens.")
+                if any(t < 0 or t >= vocab_size for t in p):
+                    raise ValueError("token id outside the vocabulary")
+        except (ValueError, TypeError) as exc:
+            return _error(400, str(exc))
+        if not params.greedy and not getattr(engine_thread.engine, "supports_random_sampling", False):
+            return _error(400, "only greedy decoding (temperature=0) is available in this build")
+
+        stream = bool(body.get("stream", False))
+        echo = bool(body.get("echo", False))
+        cmpl_id = "cmpl-" + uuid.uuid4().hex
+        loop = asyncio.get_running_loop()
+        q: asyncio.Queue = asyncio.Queue()
+        rids = [f"{cmpl_id}-{i}" for i in range(len(prompts))]
+        for i, (rid, p) in enumerate(zip(rids, prompts)):
+            engine_thread.submit(rid, p, params, lambda o, i=i: loop.call_soon_threadsafe(q.put_nowait, (i, o)))
+
+        detoks = [IncrementalDetokenizer(tokenizer) for _ in prompts]
+        texts = [tokenizer.decode(p) if echo else "" for p in prompts]
+        n_out = [0] * len(prompts)
+        reasons: List[Optional[str]] = [None] * len(prompts)
+
+        def apply_stop(i: int) -> bool:
+            """Cut text at the first stop string; True if one was hit."""
+            for s in params.stop:
+                at = texts[i].find(s, len(tokenizer.decode(prompts[i])) if echo else 0)
+                if at >= 0:
+                    texts[i] = texts[i][:at]
+                    return True
+            return False
+
+        async def events():
+            done = 0
+            sent = [len(t) if not echo else 0 for t in texts]
+            while done < len(prompts):
+                i, o = await q.get()
+                if isinstance(o, Exception):
+                    raise o
+                if reasons[i] is not None:
+                    continue
+                n_out[i] = o.num_output_tokens
+                texts[i] += detoks[i].push(o.new_token_ids)
+                hit = bool(params.stop) and apply_stop(i)
+                if hit:
+                    reasons[i] = "stop"
+                    engine_thread.abort(rids[i])
+                elif o.finished:
+                    reasons[i] = o.finish_reason
+                if reasons[i] is not None:
+                    done += 1
+                delta = texts[i][sent[i]:]
+                sent[i] = len(texts[i])
+                yield i, delta, reasons[i]
+
+        usage = lambda: {"prompt_tokens": sum(len(p) for p in prompts), "completion_tokens": sum(n_out),  # noqa: E731
+                         "total_tokens": sum(len(p) for p in prompts) + sum(n_out)}
+
+        if stream:
+            async def sse():
+                try:
+                    async for i, delta, reason in events():
+                        if delta or reason is not None:
+                            chunk = {"id": cmpl_id, "object": "text_completion", "created": int(time.time()),
+                                     "model": served_model_name,
+                                     "choices": [{"index": i, "text": delta, "logprobs": None, "finish_reason": reason}]}
+                            yield f"data: {json.dumps(chunk)}\n\n"
+                    yield "data: [DONE]\n\n"
+                except asyncio.CancelledError:
+                    for rid in rids:
+                        engine_thread.abort(rid)
+                    raise
+                except Exception as exc:
+                    yield f"data: {json.dumps({'error': {'message': str(exc), 'type': 'internal_error', 'code': 500}})}\n\n"
+            return StreamingResponse(sse(), media_type="text/event-stream")
+
+        try:
+            async for _ in events():
+                if await request.is_disconnected():
+                    for rid in rids:
+                        engine_thread.abort(rid)
+                    return _error(499, "client disconnected")
+        except ValueError as exc:
+            return _error(400, str(exc))
+        except Exception as exc:
+            return _error(500, f"engine error: {exc!r}", "internal_error")
+        return JSONResponse({"id": cmpl_id, "object": "text_completion", "created": int(time.time()),
+                             "model": served_model_name,
+                             "choices": [{"index": i, "text": texts[i], "logprobs": None, "finish_reason": reasons[i]}
+                                         for i in range(len(prompts))],
+                             "usage": usage()})
+
+    return app
+
+
+def spawn_tp_workers(tp: int, argv: List[str]):
+    """One process per GPU: the server process becomes rank 0 and starts ranks
+    1..tp-1 as children (before anything touches the GPU)."""
+    import socket
+    import subprocess
+    if tp <= 1 or "RANK" in os.environ:
+        return []
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(tp), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(1, tp):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, "-m", "mi355_decode.entrypoints.openai.api_server"] + argv, env=env))
+    os.environ.update(base, RANK="0", LOCAL_RANK="0")
+    return procs
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    logging.basicConfig(level=os.environ.get("VLLM_LOGGING_LEVEL", "INFO").upper() if
+                        os.environ.get("VLLM_LOGGING_LEVEL", "INFO").upper() in ("DEBUG", "INFO", "WARNING", "ERROR")
+                        else "INFO", format="%(asctime)s %(levelname)s %(name)s: %(message)s")
+    argv = list(sys.argv[1:] if argv is None else argv)
+    removed = sanitize_env()
+    if removed:
+        log.info("ignoring harness-set %s (GPU visibility comes from the device plugin)", removed)
+    ns, args = parse_args(argv)
+    workers = spawn_tp_workers(args.tensor_parallel_size, argv)
+    rank = int(os.environ.get("RANK", "0"))
+
+    from ...config import ModelConfig
+    from ...llm import build_engine
+    from ...serving import EngineThread
+    from ...tokenizer import load_tokenizer
+
+    cfg = ModelConfig.from_pretrained(args.model)
+    served = args.served_model_name or args.model
+    max_model_len = args.max_model_len or min(cfg.max_position_embeddings, 8192)
+    tokenizer = load_tokenizer(args.model, cfg.vocab_size)
+    if getattr(tokenizer, "is_fallback", False):
+        log.warning("no tokenizer.json under %r: text prompts are mapped byte-wise (token-id prompts are exact)", args.model)
+
+    control = None
+
+    def make_engine():
+        nonlocal control
+        eng = build_engine(args, model_config=cfg)
+        if args.tensor_parallel_size > 1:
+            import torch.distributed as dist
+            control = dist.new_group(backend="gloo")
+            thread.control_group = control
+        return eng
+
+    thread = EngineThread(make_engine, rank=rank)
+    if rank != 0:                      # TP worker: no HTTP, just follow rank 0
+        thread._run()
+        return 1 if thread.failed else 0
+
+    import uvicorn
+    app = build_app(thread, served, tokenizer, cfg.vocab_size, max_model_len)
+    thread.start()
+    config = uvicorn.Config(app, host=ns.host, port=ns.port, log_level="warning", access_log=False)
+    server = uvicorn.Server(config)
+
+    async def serve():
+        task = asyncio.create_task(server.serve())
+        while not task.done():
+            await asyncio.sleep(0.5)
+            if thread.failed is not None:            # fatal engine error: exit non-zero
+                server.should_exit = True
+        await task
+
+    asyncio.run(serve())
+    thread.shutdown()
+    for p in workers:
+        p.terminate()
+    return 1 if thread.failed is not None else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -184,9 +184,11 @@ class ModelRunner:
         """Warm up and capture the decode step for one padded batch size."""
         if bucket in self.graphs:
             return
-        # neutral inputs: padded rows store nothing and attend to nothing
-        self.slots[:bucket].fill_(-1)
-        self.ctx[:bucket].zero_()
+        # Warm-up and capture run on neutral inputs (no KV store, empty contexts) so
+        # they cannot disturb live pages; the caller's staged inputs are put back after.
+        saved64, saved32 = self.in64.clone(), self.in32.clone()
+        self.slots.fill_(-1)
+        self.ctx.zero_()
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -197,6 +199,8 @@ class ModelRunner:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._decode_body(bucket)
+        self.in64.copy_(saved64)
+        self.in32.copy_(saved32)
         self.graphs[bucket] = g
 
     def decode(self, batch: int) -> torch.Tensor:

@@ -1,0 +1,136 @@
+"""Thread-side engine loop for the HTTP server.
+
+The LLMEngine runs on its own thread so that the ASGI loop (and with it
+``GET /health``, which kubelet probes with a 5 s timeout,
+benchmark-vllm/vllm_templates.py:182-201) never waits on the GPU.  Requests enter
+through a thread-safe inbox; every generated token is handed back to the
+request's asyncio queue with ``loop.call_soon_threadsafe``.
+
+Under tensor parallelism rank 0 owns the HTTP socket; each loop iteration it
+broadcasts the requests/aborts it has collected (gloo, CPU objects) and then all
+ranks advance their identical engines by one step.
+"""
+from __future__ import annotations
+
+import logging
+import queue
+import threading
+import time
+from dataclasses import dataclass
+from typing import Callable, List, Optional
+
+from .engine import LLMEngine, RequestOutput
+from .sampling_params import SamplingParams
+
+log = logging.getLogger("mi355_decode")
+
+
+@dataclass
+class _Add:
+    request_id: str
+    prompt_ids: List[int]
+    params: SamplingParams
+    arrival: float
+
+
+@dataclass
+class _Abort:
+    request_id: str
+
+
+class EngineThread:
+    def __init__(self, make_engine: Callable[[], LLMEngine], control_group=None, rank: int = 0):
+        self._make_engine = make_engine
+        self.engine: Optional[LLMEngine] = None
+        self.inbox: "queue.Queue" = queue.Queue()
+        self.sinks = {}                      # request_id -> callable(RequestOutput | Exception)
+        self.ready = threading.Event()
+        self.failed: Optional[BaseException] = None
+        self.stop_flag = False
+        self.control_group, self.rank = control_group, rank
+        self.thread = threading.Thread(target=self._run, name="mi355-engine", daemon=True)
+        self.steps = 0
+        self.tokens_out = 0
+        self.started = time.time()
+
+    def start(self):
+        self.thread.start()
+
+    # ---- called from the server thread ---------------------------------- #
+    def submit(self, request_id: str, prompt_ids: List[int], params: SamplingParams, sink) -> None:
+        self.sinks[request_id] = sink
+        self.inbox.put(_Add(request_id, prompt_ids, params, time.perf_counter()))
+
+    def abort(self, request_id: str) -> None:
+        self.sinks.pop(request_id, None)
+        self.inbox.put(_Abort(request_id))
+
+    def shutdown(self):
+        self.stop_flag = True
+        self.inbox.put(None)
+
+    # ---- engine thread ----------------------------------------------------- #
+    def _collect(self, block: bool) -> list:
+        msgs = []
+        try:
+            if block:
+                m = self.inbox.get(timeout=0.05)
+                msgs.append(m)
+            while True:
+                msgs.append(self.inbox.get_nowait())
+        except queue.Empty:
+            pass
+        return msgs
+
+    def _exchange(self, msgs: list) -> list:
+        """Rank 0 -> all ranks: this iteration's control messages."""
+        if self.control_group is None:
+            return msgs
+        import torch.distributed as dist
+        box = [msgs if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=self.control_group)
+        return box[0]
+
+    def _run(self):
+        try:
+            self.engine = self._make_engine()
+            self.ready.set()
+            eng = self.engine
+            while True:
+                msgs = self._collect(block=not eng.has_unfinished()) if self.rank == 0 else []
+                if self.stop_flag:
+                    msgs.append(None)
+                msgs = self._exchange(msgs)
+                if any(m is None for m in msgs):
+                    break
+                for m in msgs:
+                    if isinstance(m, _Add):
+                        try:
+                            eng.add_request(m.request_id, m.prompt_ids, m.params, arrival_time=m.arrival)
+                        except Exception as exc:         # bad request: report to its sink only
+                            sink = self.sinks.pop(m.request_id, None)
+                            if sink:
+                                sink(exc)
+                    elif isinstance(m, _Abort):
+                        eng.abort_request(m.request_id)
+                if not eng.has_unfinished():
+                    continue
+                outs: List[RequestOutput] = eng.step()
+                self.steps += 1
+                for o in outs:
+                    self.tokens_out += len(o.new_token_ids)
+                    sink = self.sinks.get(o.request_id)
+                    if sink:
+                        sink(o)
+                        if o.finished:
+                            self.sinks.pop(o.request_id, None)
+        except BaseException as exc:                     # fatal: surface on /health and to waiters
+            log.exception("engine thread died")
+            self.failed = exc
+            self.ready.set()
+            for sink in list(self.sinks.values()):
+                try:
+                    sink(exc)
+                except Exception:
+                    pass
+            self.sinks.clear()

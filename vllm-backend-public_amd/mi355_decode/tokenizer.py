@@ -1,0 +1,70 @@
+"""Tokenizers.  Real models: the HF ``tokenizer.json`` in the local model
+directory, through the ``tokenizers`` library (nothing is downloaded).  When the
+directory has none (synthetic-weight benchmarking, tiny test models) text is
+mapped byte-wise onto the vocabulary so that the text routes still work; such
+output is not language, and the server says so at start-up."""
+from __future__ import annotations
+
+import os
+from typing import List
+
+
+class ByteTokenizer:
+    """UTF-8 bytes -> ids (byte + offset, folded into the vocabulary)."""
+    is_fallback = True
+
+    def __init__(self, vocab_size: int):
+        self.vocab_size = vocab_size
+        self.offset = 3 if vocab_size >= 259 else 0
+        self.bos_token_id = None
+        self.eos_token_id = None
+
+    def encode(self, text: str) -> List[int]:
+        ids = [(b + self.offset) % self.vocab_size for b in text.encode("utf-8")]
+        return ids or [self.offset % self.vocab_size]
+
+    def decode(self, ids: List[int]) -> str:
+        data = bytes(((i - self.offset) % self.vocab_size) % 256 for i in ids)
+        return data.decode("utf-8", errors="replace")
+
+
+class HFTokenizer:
+    is_fallback = False
+
+    def __init__(self, path: str, add_bos: bool = True):
+        from tokenizers import Tokenizer
+        self.tk = Tokenizer.from_file(path)
+        self.vocab_size = self.tk.get_vocab_size()
+        self.bos_token_id = None
+        self.eos_token_id = None
+
+    def encode(self, text: str) -> List[int]:
+        return self.tk.encode(text, add_special_tokens=True).ids
+
+    def decode(self, ids: List[int]) -> str:
+        return self.tk.decode(list(ids), skip_special_tokens=True)
+
+
+def load_tokenizer(model: str, vocab_size: int):
+    path = os.path.join(model, "tokenizer.json")
+    if os.path.isfile(path):
+        return HFTokenizer(path)
+    return ByteTokenizer(vocab_size)
+
+
+class IncrementalDetokenizer:
+    """Text delta per new token; holds back bytes of an unfinished UTF-8 sequence."""
+
+    def __init__(self, tokenizer):
+        self.tk = tokenizer
+        self.ids: List[int] = []
+        self.text = ""
+
+    def push(self, new_ids: List[int]) -> str:
+        self.ids.extend(new_ids)
+        full = self.tk.decode(self.ids)
+        if full.endswith("�"):
+            return ""
+        delta = full[len(self.text):]
+        self.text = full
+        return delta
