@@ -168,8 +168,8 @@ def cpu_baseline(cfg, batch, ctx_len, sample_layers=2, steps=2):
         w[p + "input_layernorm.weight"] = w[p + "post_attention_layernorm.weight"] = np.ones(H, np.float32)
     rc = M.RefConfig(vocab_size=V, hidden_size=H, intermediate_size=F, num_hidden_layers=sample_layers,
                      num_attention_heads=nh, num_key_value_heads=nkv, head_dim=d, rope_theta=cfg.rope_theta,
-                     rms_norm_eps=cfg.rms_norm_eps, max_position_embeddings=ctx_len + steps + 1)
-    blocks_per_seq = (ctx_len + steps + 16) // 16
+                     rms_norm_eps=cfg.rms_norm_eps, max_position_embeddings=ctx_len + 2 * steps + 8)
+    blocks_per_seq = (ctx_len + 2 * steps + 8 + 15) // 16
     model = M.RefModel(rc, w, "bfloat16", num_blocks=batch * blocks_per_seq, layers=sample_layers)
     for kc, vc in zip(model.k_cache, model.v_cache):
         kc[:] = mat(*kc.shape)
@@ -322,7 +322,10 @@ def main():
         dist.barrier()
     if rank == 0:
         if not a.no_cpu_baseline and a.gpus == 1:
-            result["cpu_baseline"] = cpu_baseline(cfg, a.batch_per_gpu, int(mean_ctx))
+            try:
+                result["cpu_baseline"] = cpu_baseline(cfg, a.batch_per_gpu, int(mean_ctx))
+            except Exception as exc:                      # never lose the GPU measurement
+                result["cpu_baseline"] = {"value": None, "error": repr(exc)}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
