@@ -183,6 +183,22 @@ int32_t mi355_argmax(int64_t* out_ids, const void* logits,
                      int64_t logits_stride, int32_t num_rows, int32_t vocab,
                      int32_t logits_dtype, void* stream);
 
+/*
+ * Decode-time linear layer  y[M, N] = x[M, K] . W[N, K]^T (+ bias[N]),  M <= 128:
+ * the weight matrix is streamed from HBM exactly once (fp32 accumulation on the
+ * matrix cores, one rounding of the result).  W row-major [N, K] contiguous;
+ * x, y row-major with the given row strides; bias may be NULL.  K must be a
+ * multiple of 32.  k_slices: 0 = choose, or 1/2/4 waves splitting K per 16-row
+ * tile of W (partial sums are combined in a fixed order: results do not depend
+ * on scheduling).  Replaces the engine's qkv/o/gate_up/down/lm_head GEMMs at
+ * decode batch sizes (--max-num-seqs, vllm_templates.py:53), which carry ~95 %
+ * of the bytes a decode step moves.
+ */
+int32_t mi355_linear_decode(void* y, int64_t y_stride, const void* x,
+                            int64_t x_stride, const void* weight,
+                            const void* bias, int32_t M, int32_t N, int32_t K,
+                            int32_t k_slices, int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,139 @@
+"""Launch, drive and ingest contracts with the reference harness (CPU only).
+
+* Launch: the container args the reference's own templates produce for the
+  BASELINE configs and its YAML fixtures (tests/golden/harness_launch.json,
+  captured from benchmark-vllm/vllm_templates.py + models.py) must parse in this
+  engine's CLI to the same settings, with no error.
+* Helm path / release naming / result keys / template substitution: restated in
+  oracle/harness_ref.py from the cited lines, pinned by hand-derived known answers.
+* Ingest: payloads built by mi355_decode.harness pass the reference's
+  EvaluationPayload validation (golden accept/reject table)."""
+import json
+import os
+
+import pytest
+
+from conftest import GOLDEN
+from mi355_decode.entrypoints.cli_args import parse_args, sanitize_env
+from mi355_decode.harness import evaluation_payload, result_pk
+from oracle import harness_ref as HR
+
+LAUNCH = json.load(open(os.path.join(GOLDEN, "harness_launch.json")))
+RESULTS = json.load(open(os.path.join(GOLDEN, "harness_results.json")))
+
+
+@pytest.mark.parametrize("case", sorted(LAUNCH["cases"]))
+@pytest.mark.parametrize("kind", ["deployment", "statefulset"])
+def test_reference_generated_args_parse(case, kind):
+    rec = LAUNCH["cases"][case]
+    cfg, args = rec["config"], rec[kind]["args"]
+    if cfg["pipeline_parallel_size"] != 1:
+        with pytest.raises(ValueError, match="pipeline"):
+            parse_args(args)
+        return
+    ns, ea = parse_args(args)
+    assert ea.model == cfg["model_name"]
+    assert ea.served_model_name == cfg["served_model_name"]
+    assert ns.port == cfg["port"] and ns.host == cfg["host"]
+    assert ea.max_num_seqs == cfg["max_num_seqs"]
+    assert ea.tensor_parallel_size == cfg["tensor_parallel_size"]
+    assert ea.max_model_len == cfg["max_model_len"]
+    assert ea.block_size == cfg["block_size"]
+    assert ea.gpu_memory_utilization == cfg["gpu_memory_utilization"]
+    assert ea.quantization == cfg["quantization"]
+    assert ea.dtype == cfg["dtype"]
+    assert ea.resolved_dtype() in ("bfloat16", "float16")
+    # the templates always force these; they are accepted and non-binding
+    assert ea.extra["device"] == "cpu" and ea.extra["enforce-eager"] == "advisory"
+    assert ea.enforce_eager is False
+    # the harness repeats its default flags after the hard-coded ones: no error, same meaning
+    assert args.count("--enforce-eager") >= 1
+
+
+def test_golden_args_are_what_the_survey_recorded():
+    a = LAUNCH["cases"]["cfg1_opt125m_cpu"]["deployment"]
+    assert a["image"] == "vllm-cpu-env:latest" and a["resources"]["requests"] == {"cpu": "4000m", "memory": "16Gi"}
+    assert a["args"][-4:] == ["--disable-log-stats", "--disable-log-requests", "--enforce-eager", "--disable-custom-all-reduce"]
+    c3 = LAUNCH["cases"]["cfg3_llama3_8b_tp4"]["deployment"]["resources"]["requests"]
+    assert c3 == {"cpu": "16000m", "memory": "128Gi", "amd.com/gpu": "4"}
+    assert LAUNCH["sanitize_k8s_name"]["meta-llama/Meta-Llama-3-8B"] == "meta-llama-meta-llama-3-8b"
+    assert LAUNCH["sanitize_k8s_name"]["3B_model.v2"] == "v3b-model-v2"
+
+
+def test_cli_duplicates_unknown_flags_and_pp():
+    ns, ea = parse_args(["--model", "a", "--model", "b", "--port", "1", "--port", "9000", "--some-new-flag", "7",
+                         "--another-switch", "--swap-space", "0", "--cpu-offload-gb", "0", "--load-format", "auto"])
+    assert ea.model == "b" and ns.port == 9000
+    assert ea.extra["some-new-flag"] == "7" and ea.extra["another-switch"] is True and ea.extra["swap-space"] == "0"
+    with pytest.raises(ValueError, match="pipeline"):
+        parse_args(["--model", "m", "--pipeline-parallel-size", "2"])
+    with pytest.raises(ValueError, match="quantization"):
+        parse_args(["--model", "m", "--quantization", "awq"])
+    _, ea = parse_args(["--model", "m", "--quantization", "fp8", "--dtype", "float32"])
+    assert ea.quantization == "fp8" and ea.resolved_dtype() == "bfloat16"
+
+
+def test_helm_path_args_parse():
+    """Args of the live (Helm) path, restated from vllm_manager.py:399-416,451-456."""
+    extra = {"disable-log-stats": True, "disable-log-requests": True, "enforce-eager": True,
+             "disable-custom-all-reduce": True}
+    gpu = HR.helm_args("/data/local_models/Meta-Llama-3-8B", "llama-3-8b", "0.0.0.0", 8000, None, extra, "amd.com/gpu", 1)
+    assert gpu == ["--model", "/data/local_models/Meta-Llama-3-8B", "--served-model-name", "llama-3-8b", "--host",
+                   "0.0.0.0", "--port", "8000", "--disable-log-stats", "--disable-log-requests", "--enforce-eager",
+                   "--disable-custom-all-reduce"]
+    ns, ea = parse_args(gpu)
+    assert ea.model.endswith("Meta-Llama-3-8B") and ea.served_model_name == "llama-3-8b" and ns.port == 8000
+    cpu = HR.helm_args("facebook/opt-125m", None, "0.0.0.0", 8000, "fp8", extra, "cpu", 0)
+    assert cpu[2:4] == ["--served-model-name", "facebook/opt-125m"] and cpu[-3:] == ["--device", "cpu", "--enforce-eager", "--disable-custom-all-reduce"][-3:]
+    _, ea = parse_args(cpu)
+    assert ea.quantization == "fp8"
+
+
+def test_env_the_harness_injects_is_sanitised():
+    for env_list in (LAUNCH["cases"]["cfg2_llama3_8b_tp1"]["deployment"]["env"], HR.helm_env("amd.com/gpu", 1),
+                     HR.helm_env("cpu", 0)):
+        env = {e["name"]: e["value"] for e in env_list}
+        assert "CUDA_VISIBLE_DEVICES" in env            # the trap: "" or "0" would hide the allocated GPUs
+        env["ROCR_VISIBLE_DEVICES"] = "0,1,2,3"
+        removed = sanitize_env(env)
+        assert "CUDA_VISIBLE_DEVICES" not in env and "CUDA_VISIBLE_DEVICES" in removed
+        assert env["ROCR_VISIBLE_DEVICES"] == "0,1,2,3"
+    keep = {"CUDA_VISIBLE_DEVICES": "2", "MI355_KEEP_CUDA_VISIBLE_DEVICES": "1"}
+    assert sanitize_env(keep) == {} and keep["CUDA_VISIBLE_DEVICES"] == "2"
+
+
+def test_release_name_pk_and_template_known_answers():
+    # benchmark-results/README.md:111
+    ka = RESULTS["pk_known_answer"]
+    assert HR.result_pk(ka["timestamp"], ka["benchmark_name"], ka["run_id"]) == ka["pk"]
+    assert HR.result_pk("t", "b", None) == "t-b-None"
+    # benchmark-eval/main.py:57
+    assert HR.process_template("{model_name}|{model_name_lower}|{inference_engine_url}", "A-b", "http://x") == "A-b|a-b|http://x"
+    assert HR.evaluation_model_name("Llama_3.1_8B") == "Llama-3-1-8B"
+    # vllm_manager.py:345-358
+    assert HR.release_name("meta-llama/Meta_Llama-3-8B", "amd.com/gpu", 4, "s", "0123456789abcdef") == \
+        "vllm-meta-llama-meta-llama-3-8b-01234567-gpu-4"
+    import hashlib
+    h = hashlib.md5(b"m/x-cpu-0-test-model-cpu").hexdigest()[:8]
+    assert HR.release_name("m/x", "cpu", 0, "test-model-cpu") == f"vllm-m-x-{h}-cpu-0"
+
+
+@pytest.mark.parametrize("case", sorted(RESULTS["cases"]))
+def test_ingest_validation_matches_reference(case):
+    rec = RESULTS["cases"][case]
+    assert HR.payload_accepted(rec["payload"]) == rec["accepted"]
+    if rec["accepted"]:
+        doc = HR.stored_document(rec["payload"])
+        assert doc["pk"].startswith(rec["payload"]["timestamp"] + "-" + rec["payload"]["benchmark_name"])
+        if case == "data_json_string":
+            assert doc["data"] == {"a": 1}
+        if case == "data_plain_string":
+            assert doc["data"] == "not json"
+
+
+def test_bench_client_payload_is_ingestible():
+    p = evaluation_payload("mi355-decode-bench", {"decode_tok_s": 6421.5, "ttft_ms_p50": 44.8}, "llama-3-8b")
+    assert HR.payload_accepted(p) and isinstance(p["run_id"], str) and p["run_id"]
+    assert set(p) == set(RESULTS["cases"]["full"]["payload"])
+    assert result_pk(p) == HR.stored_document(p)["pk"]
+    json.dumps(p)                                         # wire format

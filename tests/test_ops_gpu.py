@@ -357,3 +357,44 @@ def test_argmax_golden_and_nan(ops, ops_golden):
     lg = ops_golden["argmax_logits"]
     out = ops.argmax(torch.from_numpy(lg).cuda())
     np.testing.assert_array_equal(out.cpu().numpy(), ops_golden["argmax_idx"])
+
+
+# --------------------------------------------------------------------------- #
+# decode-time linear layer (weights streamed once; fp32 accumulation, one rounding)
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,N,K,bias", [(1, 64, 256, False), (4, 320, 256, True), (32, 4096, 4096, False),
+                                        (32, 6144, 4096, True), (7, 1000, 448, False), (33, 512, 1024, True),
+                                        (128, 768, 512, False), (17, 100, 96, True)])
+@pytest.mark.parametrize("mode", [0, 1, 2, 4, 101, 102])
+def test_linear_decode(ops, dtype, M, N, K, bias, mode):
+    if mode >= 100 and K % 256:
+        pytest.skip("LDS-staged variant needs K % 256 == 0")
+    rng = rng_for("linear", dtype, M, N, K)
+    x = grid(rng, (M, K), dtype)
+    w = grid(rng, (N, K), dtype, 0.05)
+    b = grid(rng, (N,), dtype) if bias else None
+    ref64 = x.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
+    y = ops.linear_decode(dev(x, dtype), dev(w, dtype), dev(b, dtype) if bias else None, k_slices=mode)
+    got = host(y)
+    # fp32 accumulation in another order than the reference, then one rounding:
+    # within one ulp of the exactly rounded result (plus fp32 summation noise)
+    tol = ULP[dtype] * np.abs(ref64) * 1.01 + 1e-5 * np.sqrt(K) * np.abs(x).max() * np.abs(w).max() + 2 * SUBNORMAL_STEP[dtype]
+    err = np.abs(got - ref64)
+    assert (err <= tol).all(), f"max err {err.max()} at ref {ref64.flat[err.argmax()]}"
+    # and mostly identical to the oracle's rounding of the fp32 product
+    exact = R.linear(x, w, b, dtype)
+    assert (got != exact).mean() <= 0.02
+
+
+def test_linear_decode_strided_out_and_in(ops):
+    """x and y as column slices of wider buffers (how the engine packs activations)."""
+    dtype = "bfloat16"
+    rng = rng_for("linear-strided")
+    xb, w = grid(rng, (8, 1024), dtype), grid(rng, (256, 512), dtype, 0.05)
+    yb = torch.zeros(8, 640, dtype=torch.bfloat16, device="cuda")
+    xd = dev(xb, dtype)
+    ops.linear_decode(xd[:, 256:768], dev(w, dtype), out=yb[:, 128:384])
+    ref = R.linear(xb[:, 256:768], w, None, dtype)
+    assert (host(yb[:, 128:384]) != ref).mean() <= 0.02
+    assert float(yb[:, :128].abs().max()) == 0.0 and float(yb[:, 384:].abs().max()) == 0.0

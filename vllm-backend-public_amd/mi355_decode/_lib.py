@@ -10,6 +10,11 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int32, c_int64, c_void_p
 
+# PyTorch bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must be the
+# one already mapped when libmi355_decode.so resolves its libamdhip64 dependency:
+# with two runtimes in one process the second one finds no device.  Hence torch first.
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355_DECODE_LIB", os.path.join(_HERE, "libmi355_decode.so"))
 
@@ -43,6 +48,7 @@ def _load() -> ctypes.CDLL:
                                            F, I32, P]),
         "mi355_silu_and_mul": (I32, [P, P, I64, I64, I32, I32, P]),
         "mi355_argmax": (I32, [P, P, I64, I32, I32, I32, P]),
+        "mi355_linear_decode": (I32, [P, I64, P, I64, P, P, I32, I32, I32, I32, I32, P]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
@@ -56,7 +62,8 @@ def _load() -> ctypes.CDLL:
 lib = _load()
 EXPORTS = ("mi355_abi_version", "mi355_last_error", "mi355_target_arch", "mi355_rms_norm",
            "mi355_fused_add_rms_norm", "mi355_rope_kv_write", "mi355_paged_attn_decode_workspace",
-           "mi355_paged_attn_decode", "mi355_paged_attn_prefill", "mi355_silu_and_mul", "mi355_argmax")
+           "mi355_paged_attn_decode", "mi355_paged_attn_prefill", "mi355_silu_and_mul", "mi355_argmax",
+           "mi355_linear_decode")
 
 
 def check(status: int) -> None:

@@ -188,3 +188,26 @@ def argmax(logits: torch.Tensor, out: torch.Tensor | None = None):
     check(lib.mi355_argmax(out.data_ptr(), logits.data_ptr(), _rows(logits, "logits"), B, V,
                            _DT[logits.dtype], _stream()))
     return out
+
+
+LINEAR_DECODE_MAX_M = 128
+
+
+def linear_decode(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None,
+                  out: torch.Tensor | None = None, k_slices: int = 0):
+    """y = x @ weight.T (+ bias) for decode batches (M <= 128): weights streamed once."""
+    dt = _dt16(x, "x")
+    _dev(weight, "weight")
+    M, K = x.shape
+    if weight.dtype != x.dtype or weight.dim() != 2 or weight.shape[1] != K or not weight.is_contiguous():
+        raise ValueError("weight must be contiguous [N, K] in the dtype of x")
+    N = weight.shape[0]
+    if bias is not None and (bias.dtype != x.dtype or bias.numel() != N or not bias.is_contiguous()):
+        raise ValueError("bias must be contiguous [N] in the dtype of x")
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    elif out.dtype != x.dtype or tuple(out.shape) != (M, N):
+        raise ValueError("out must be [M, N] in the dtype of x")
+    check(lib.mi355_linear_decode(out.data_ptr(), _rows(out, "out"), x.data_ptr(), _rows(x, "x"), weight.data_ptr(),
+                                  bias.data_ptr() if bias is not None else 0, M, N, K, int(k_slices), dt, _stream()))
+    return out
