@@ -1,0 +1,162 @@
+"""HTTP contract of the server (routes the harness calls), on CPU: the real
+FastAPI app and the real engine thread + scheduler, with the GPU model runner
+replaced by the test double of test_engine_cpu.py."""
+import json
+import threading
+import time
+
+import pytest
+from fastapi.testclient import TestClient
+
+from mi355_decode.engine import LLMEngine
+from mi355_decode.entrypoints.openai.api_server import build_app, normalise_prompts
+from mi355_decode.serving import EngineThread
+from mi355_decode.tokenizer import ByteTokenizer, IncrementalDetokenizer
+from test_engine_cpu import FakeRunner, V, reference
+
+
+def make(delay=0.0, fail=False):
+    gate = threading.Event()
+
+    def factory():
+        if delay:
+            gate.wait(delay)
+        if fail:
+            raise RuntimeError("cannot load weights")
+        return LLMEngine(FakeRunner(256, 8, 512), 8, 128, 512)
+
+    th = EngineThread(factory)
+    tok = ByteTokenizer(V)
+    app = build_app(th, "test-model", tok, V, 512)
+    th.start()
+    return th, TestClient(app), gate, tok
+
+
+def test_health_and_models_503_until_ready_then_200():
+    th, c, gate, _ = make(delay=30)
+    assert c.get("/health").status_code == 503              # socket is up, engine still loading
+    assert c.get("/v1/models").status_code == 503
+    gate.set()
+    assert th.ready.wait(10)
+    assert c.get("/health").status_code == 200 and c.get("/health").content == b""
+    r = c.get("/v1/models")
+    assert r.status_code == 200 and r.json()["object"] == "list" and r.json()["data"][0]["id"] == "test-model"
+    th.shutdown()
+
+
+def test_fatal_engine_error_turns_health_500():
+    th, c, _, _ = make(fail=True)
+    th.thread.join(10)
+    assert c.get("/health").status_code == 500
+    assert c.post("/v1/completions", json={"prompt": [1, 2], "max_tokens": 2}).status_code == 500
+
+
+def test_completion_token_ids_and_usage():
+    th, c, _, tok = make()
+    th.ready.wait(10)
+    prompt = [5, 6, 7, 8]
+    r = c.post("/v1/completions", json={"model": "test-model", "prompt": prompt, "max_tokens": 6, "temperature": 0})
+    assert r.status_code == 200
+    body = r.json()
+    assert body["object"] == "text_completion" and body["model"] == "test-model" and body["id"].startswith("cmpl-")
+    ch = body["choices"][0]
+    assert ch["index"] == 0 and ch["finish_reason"] == "length" and ch["logprobs"] is None
+    assert ch["text"] == tok.decode(reference(prompt, 6))
+    assert body["usage"] == {"prompt_tokens": 4, "completion_tokens": 6, "total_tokens": 10}
+    th.shutdown()
+
+
+def test_batch_prompts_text_and_echo():
+    th, c, _, tok = make()
+    th.ready.wait(10)
+    r = c.post("/v1/completions", json={"prompt": ["hello", "wor"], "max_tokens": 3, "temperature": 0, "echo": True})
+    assert r.status_code == 200
+    chs = sorted(r.json()["choices"], key=lambda x: x["index"])
+    for ch, text in zip(chs, ["hello", "wor"]):
+        assert ch["text"] == text + tok.decode(reference(tok.encode(text), 3))
+    r = c.post("/v1/completions", json={"prompt": [[1, 2, 3], [4, 5]], "max_tokens": 2, "temperature": 0})
+    assert len(r.json()["choices"]) == 2 and r.json()["usage"]["prompt_tokens"] == 5
+    th.shutdown()
+
+
+def test_streaming_sse():
+    th, c, _, tok = make()
+    th.ready.wait(10)
+    prompt = [9, 8, 7]
+    with c.stream("POST", "/v1/completions", json={"prompt": prompt, "max_tokens": 5, "temperature": 0, "stream": True}) as r:
+        assert r.status_code == 200 and r.headers["content-type"].startswith("text/event-stream")
+        lines = [ln for ln in r.iter_lines() if ln]
+    assert lines[-1] == "data: [DONE]"
+    chunks = [json.loads(ln[6:]) for ln in lines[:-1]]
+    assert all(ch["object"] == "text_completion" for ch in chunks)
+    assert "".join(ch["choices"][0]["text"] for ch in chunks) == tok.decode(reference(prompt, 5))
+    assert chunks[-1]["choices"][0]["finish_reason"] == "length"
+    assert all(ch["choices"][0]["finish_reason"] is None for ch in chunks[:-1])
+    th.shutdown()
+
+
+def test_stop_string_cuts_text_and_aborts():
+    th, c, _, tok = make()
+    th.ready.wait(10)
+    prompt = [3, 1, 4, 1, 5]
+    full = tok.decode(reference(prompt, 40))
+    stop = full[5:7]
+    r = c.post("/v1/completions", json={"prompt": prompt, "max_tokens": 40, "temperature": 0, "stop": stop})
+    ch = r.json()["choices"][0]
+    assert ch["finish_reason"] == "stop" and ch["text"] == full[: full.find(stop)]
+    deadline = time.time() + 5
+    while th.engine.has_unfinished() and time.time() < deadline:
+        time.sleep(0.01)
+    assert not th.engine.has_unfinished()                   # the aborted sequence released its pages
+    th.shutdown()
+
+
+def test_errors_are_openai_style_json():
+    th, c, _, _ = make()
+    th.ready.wait(10)
+    for body, code in [({"max_tokens": 3}, 400), ({"prompt": [1], "model": "other"}, 404),
+                       ({"prompt": [1], "n": 2}, 400), ({"prompt": [V + 5]}, 400), ({"prompt": []}, 400),
+                       ({"prompt": list(range(600))}, 400), ({"prompt": [1], "max_tokens": 0}, 400),
+                       ({"prompt": [1], "temperature": 0.7}, 400)]:
+        r = c.post("/v1/completions", json=body)
+        assert r.status_code == code, (body, r.text)
+        err = r.json()["error"]
+        assert set(err) >= {"message", "type", "code"}
+    assert c.post("/v1/completions", content=b"{not json").status_code == 400
+    th.shutdown()
+
+
+def test_many_concurrent_requests_and_health_stays_fast():
+    th, c, _, tok = make()
+    th.ready.wait(10)
+    results = {}
+
+    def one(i):
+        p = [i + 1, i + 2, i + 3]
+        r = c.post("/v1/completions", json={"prompt": p, "max_tokens": 8, "temperature": 0})
+        results[i] = (r.status_code, r.json()["choices"][0]["text"], tok.decode(reference(p, 8)))
+
+    ts = [threading.Thread(target=one, args=(i,)) for i in range(24)]
+    [t.start() for t in ts]
+    t0 = time.time()
+    assert c.get("/health").status_code == 200 and time.time() - t0 < 5.0     # kubelet probe timeout is 5 s
+    [t.join(60) for t in ts]
+    assert len(results) == 24 and all(s == 200 and a == b for s, a, b in results.values())
+    m = c.get("/metrics").text
+    assert "mi355_generation_tokens_total" in m and "mi355_kv_blocks_free" in m
+    th.shutdown()
+
+
+def test_prompt_normalisation_and_detokenizer():
+    tok = ByteTokenizer(1000)
+    assert normalise_prompts("ab", tok, 1000) == [tok.encode("ab")]
+    assert normalise_prompts(["a", "b"], tok, 1000) == [tok.encode("a"), tok.encode("b")]
+    assert normalise_prompts([1, 2, 3], tok, 1000) == [[1, 2, 3]]
+    assert normalise_prompts([[1], [2, 3]], tok, 1000) == [[1], [2, 3]]
+    for bad in ([], [[]], [1, "a"], 5, [True]):
+        with pytest.raises(ValueError):
+            normalise_prompts(bad, tok, 1000)
+    d = IncrementalDetokenizer(tok)
+    ids = tok.encode("héllo")                               # multi-byte char split over two tokens
+    out = "".join(d.push([i]) for i in ids)
+    assert out == "héllo"

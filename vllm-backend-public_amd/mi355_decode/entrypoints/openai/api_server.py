@@ -26,7 +26,10 @@ import os
 import sys
 import time
 import uuid
-from typing import List, Optional, Union
+from typing import List, Optional
+
+from fastapi import FastAPI, Request
+from fastapi.responses import JSONResponse, Response, StreamingResponse
 
 from ..cli_args import parse_args, sanitize_env
 
@@ -34,7 +37,6 @@ log = logging.getLogger("mi355_decode")
 
 
 def _error(status: int, message: str, etype: str = "invalid_request_error"):
-    from fastapi.responses import JSONResponse
     return JSONResponse(status_code=status,
                         content={"error": {"message": message, "type": etype, "param": None, "code": status}})
 
@@ -55,9 +57,6 @@ def normalise_prompts(prompt, tokenizer, vocab_size: int) -> List[List[int]]:
 
 
 def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int, max_model_len: int):
-    from fastapi import FastAPI, Request
-    from fastapi.responses import JSONResponse, Response, StreamingResponse
-
     from ...sampling_params import SamplingParams
     from ...tokenizer import IncrementalDetokenizer
 
@@ -181,7 +180,7 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
                 if reasons[i] is not None:
                     continue
                 n_out[i] = o.num_output_tokens
-                texts[i] += detoks[i].push(o.new_token_ids)
+                texts[i] += detoks[i].push(o.new_token_ids, final=o.finished)
                 hit = bool(params.stop) and apply_stop(i)
                 if hit:
                     reasons[i] = "stop"

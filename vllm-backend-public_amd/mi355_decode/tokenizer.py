@@ -60,10 +60,10 @@ class IncrementalDetokenizer:
         self.ids: List[int] = []
         self.text = ""
 
-    def push(self, new_ids: List[int]) -> str:
+    def push(self, new_ids: List[int], final: bool = False) -> str:
         self.ids.extend(new_ids)
         full = self.tk.decode(self.ids)
-        if full.endswith("�"):
+        if full.endswith("\ufffd") and not final:
             return ""
         delta = full[len(self.text):]
         self.text = full
