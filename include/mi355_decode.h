@@ -184,6 +184,26 @@ int32_t mi355_argmax(int64_t* out_ids, const void* logits,
                      int32_t logits_dtype, void* stream);
 
 /*
+ * Random sampling with temperature, top-k and top-p, one row per sequence.
+ * Candidates = the k highest logits (k = top_k[b] if 0 < top_k[b] <= 1024, else
+ * 1024; ties at the threshold by lowest index) ordered by (logit desc, index
+ * asc); w_i = exp((logit_i - logit_0) / temperature[b]); top_p[b] < 1 keeps the
+ * shortest prefix whose cumulative weight reaches top_p * total; one uniform
+ * number from a counter hash of (seeds[b], steps[b]) picks the token by inverse
+ * CDF.  All of it is fixed-order fp32 arithmetic: a (logits, parameters, seed,
+ * step) tuple always yields the same token, on any launch.  Rows with
+ * temperature[b] <= 0 get the greedy token (mi355_argmax semantics).  Serves
+ * temperature/top_k/top_p/seed of POST /v1/completions
+ * (benchmark-deployer/docs/deployment/post_run.md:46).
+ */
+int32_t mi355_sample_topk_topp(int64_t* out_ids, const void* logits,
+                               int64_t logits_stride, int32_t num_rows,
+                               int32_t vocab, int32_t logits_dtype,
+                               const float* temperature, const int32_t* top_k,
+                               const float* top_p, const int64_t* seeds,
+                               const int64_t* steps, void* stream);
+
+/*
  * Decode-time linear layer  y[M, N] = x[M, K] . W[N, K]^T (+ bias[N]),  M <= 128:
  * the weight matrix is streamed from HBM exactly once (fp32 accumulation on the
  * matrix cores, one rounding of the result).  W row-major [N, K] contiguous;

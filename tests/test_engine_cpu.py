@@ -58,7 +58,8 @@ class FakeRunner:
         assert (toks >= 0).all(), "read a slot that was never written"
         return toks.tolist()
 
-    def run_decode(self, n):
+    def run_decode(self, n, sampling=None):
+        self.last_sampling = sampling
         B = self.max_num_seqs
         ids, pos, slots = self.h64[:B], self.h64[B:2 * B], self.h64[2 * B:]
         ctx, bt = self.h32[:B], self.h32[B:].reshape(B, self.max_blocks)
@@ -71,7 +72,9 @@ class FakeRunner:
         self.decode_batches.append(n)
         return out
 
-    def run_prefill(self, token_ids, positions, slot_mapping, block_tables, cu_seqlens, context_lens, max_q_len):
+    def run_prefill(self, token_ids, positions, slot_mapping, block_tables, cu_seqlens, context_lens, max_q_len,
+                    sampling=None):
+        self.last_sampling = sampling
         assert len(token_ids) == len(positions) == len(slot_mapping) == cu_seqlens[-1]
         self.cache[slot_mapping] = token_ids
         out = []
@@ -228,3 +231,19 @@ def test_late_arrivals_join_running_batch():
             got.setdefault(k, []).extend(v)
     for i, p in enumerate(ps):
         assert got[f"r{i}"] == reference(p, 12)
+
+
+def test_sampling_parameters_reach_the_runner():
+    eng, runner = make_engine()
+    eng.add_request("g", [1, 2, 3], SamplingParams(max_tokens=3, temperature=0.0))
+    eng.step()
+    assert runner.last_sampling is None                       # all greedy: no sampler launch
+    eng.add_request("r", [4, 5], SamplingParams(max_tokens=3, temperature=0.7, top_k=5, top_p=0.9, seed=42))
+    eng.step()                                                # prefill of "r"
+    s = runner.last_sampling
+    assert s["temperature"].tolist() == [np.float32(0.7)] and s["top_k"].tolist() == [5] and s["seeds"].tolist() == [42]
+    eng.step()                                                # decode of both
+    s = runner.last_sampling
+    assert s["temperature"].tolist() == [0.0, np.float32(0.7)] and s["steps"].tolist() == [1, 1]
+    eng.add_request("u", [9], SamplingParams(max_tokens=2, temperature=1.0))      # no seed: engine draws one
+    assert 0 <= eng.seqs["u"].seed < 2 ** 62

@@ -207,3 +207,47 @@ def test_preemption_on_gpu_keeps_tokens():
     tight.sched = Scheduler(tight.alloc, 4, 8192, 128)
     _oracle_checked(tight, cfg, w, prompts, 40, "preempting engine")
     assert tight.stats["preemptions"] > 0
+
+
+def test_random_sampling_through_the_engine():
+    """Seeded sampling is reproducible, differs across seeds, and the first sampled
+    token equals the CPU restatement applied to the engine's own prefill logits."""
+    from mi355_decode.sampling_params import SamplingParams
+    name = "llama_d128"
+    eng, cfg, w = build(name, "bfloat16")
+    prompts = make_prompts(name, len(LENGTHS), LENGTHS)
+
+    def gen(seed, temperature=0.9, top_k=30, top_p=0.95):
+        out = {i: [] for i in range(len(prompts))}
+        for i, p in enumerate(prompts):
+            eng.add_request(f"s{seed}-{i}", [int(t) for t in p],
+                            SamplingParams(max_tokens=12, temperature=temperature, top_k=top_k, top_p=top_p,
+                                           seed=seed + i, ignore_eos=True))
+        while eng.has_unfinished():
+            for o in eng.step():
+                out[int(o.request_id.split("-")[1])].extend(o.new_token_ids)
+        return np.array([out[i] for i in range(len(prompts))])
+
+    a, b, c = gen(100), gen(100), gen(200)
+    np.testing.assert_array_equal(a, b)
+    assert (a != c).any()
+    # first token: the oracle sampler on the logits the engine produced
+    r = eng.runner
+    lens = [len(p) for p in prompts]
+    bt = np.zeros((len(prompts), r.max_blocks), np.int32)
+    for i in range(len(prompts)):
+        bt[i, :8] = np.arange(i * 8, i * 8 + 8)
+    dev = r.device
+    slots = np.concatenate([bt[i, np.arange(n) // 16].astype(np.int64) * 16 + np.arange(n) % 16 for i, n in enumerate(lens)])
+    _, logits = r.prefill(torch.from_numpy(np.concatenate(prompts)).to(dev),
+                          torch.from_numpy(np.concatenate([np.arange(n) for n in lens])).to(dev),
+                          torch.from_numpy(slots).to(dev), torch.from_numpy(bt).to(dev),
+                          torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(dev),
+                          torch.tensor(lens, dtype=torch.int32, device=dev), max(lens))
+    n = len(prompts)
+    want = R.sample_topk_topp(logits.float().cpu().numpy(), np.full(n, 0.9, np.float32), np.full(n, 30, np.int32),
+                              np.full(n, 0.95, np.float32), np.arange(100, 100 + n), np.zeros(n, np.int64))
+    np.testing.assert_array_equal(a[:, 0], want)
+    # temperature -> greedy limit: top_k = 1 is argmax whatever the seed
+    g1 = gen(300, temperature=1.0, top_k=1, top_p=1.0)
+    np.testing.assert_array_equal(g1, engine_generate(eng, prompts, 12))

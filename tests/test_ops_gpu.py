@@ -398,3 +398,48 @@ def test_linear_decode_strided_out_and_in(ops):
     ref = R.linear(xb[:, 256:768], w, None, dtype)
     assert (host(yb[:, 128:384]) != ref).mean() <= 0.02
     assert float(yb[:, :128].abs().max()) == 0.0 and float(yb[:, 384:].abs().max()) == 0.0
+
+
+# --------------------------------------------------------------------------- #
+# random sampling: bit-exact token ids (fixed-order fp32 algorithm on both sides)
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("ldt", ["float32", "bfloat16", "float16"])
+@pytest.mark.parametrize("B,V", [(8, 1000), (32, 128256), (5, 696), (16, 50272)])
+def test_sample_topk_topp(ops, ldt, B, V):
+    rng = rng_for("sample", ldt, B, V)
+    lg = R.round_to((rng.standard_normal((B, V)) * 3).astype(np.float32), ldt)
+    lg[0, :] = 0.0                                          # all tied: index order decides
+    lg[0, 5] = -0.0
+    if B > 2:
+        lg[1, : V // 2] = lg[1, 0]                          # a huge tie that straddles the top-k threshold
+        lg[2, 7] = np.nan                                   # NaN is never a candidate
+    temperature = rng.choice([0.0, 0.3, 0.7, 1.0, 1.5], B).astype(np.float32)
+    temperature[:3] = [1.0, 0.8, 1.2][: min(3, B)]
+    top_k = rng.choice([-1, 1, 2, 5, 40, 1024, 5000], B).astype(np.int32)
+    top_p = rng.choice([1.0, 0.95, 0.5, 0.1], B).astype(np.float32)
+    seeds = rng.integers(0, 2 ** 62, B).astype(np.int64)
+    tdt = {"float32": torch.float32, **DT}[ldt]
+    lgd = torch.from_numpy(lg).to(tdt).cuda()
+    for step in (0, 1, 17):
+        steps = np.full(B, step, np.int64) + np.arange(B)
+        ref = R.sample_topk_topp(lg, temperature, top_k, top_p, seeds, steps)
+        out = ops.sample(lgd, torch.from_numpy(temperature).cuda(), torch.from_numpy(top_k).cuda(),
+                         torch.from_numpy(top_p).cuda(), torch.from_numpy(seeds).cuda(), torch.from_numpy(steps).cuda())
+        np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+def test_sample_distribution(ops):
+    """Frequencies over many (seed, step) pairs follow softmax(logits / T) over the top-k."""
+    rng = rng_for("sample-dist")
+    V, k, T, n = 4096, 8, 0.8, 4096
+    row = R.round_to((rng.standard_normal(V) * 2).astype(np.float32), "bfloat16")
+    lg = torch.from_numpy(np.tile(row, (n, 1))).to(torch.bfloat16).cuda()
+    out = ops.sample(lg, torch.full((n,), T, device="cuda"), torch.full((n,), k, dtype=torch.int32, device="cuda"),
+                     torch.ones(n, device="cuda"), torch.arange(n, device="cuda") * 7919 + 3,
+                     torch.arange(n, device="cuda")).cpu().numpy()
+    top = np.argsort(-row.astype(np.float64), kind="stable")[:k]
+    p = np.exp((row[top] - row[top].max()) / T)
+    p /= p.sum()
+    assert set(out) <= set(top)
+    freq = np.array([(out == t).mean() for t in top])
+    assert np.abs(freq - p).max() < 4 * np.sqrt(p.max() / n) + 0.01

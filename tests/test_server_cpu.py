@@ -117,12 +117,24 @@ def test_errors_are_openai_style_json():
     for body, code in [({"max_tokens": 3}, 400), ({"prompt": [1], "model": "other"}, 404),
                        ({"prompt": [1], "n": 2}, 400), ({"prompt": [V + 5]}, 400), ({"prompt": []}, 400),
                        ({"prompt": list(range(600))}, 400), ({"prompt": [1], "max_tokens": 0}, 400),
-                       ({"prompt": [1], "temperature": 0.7}, 400)]:
+                       ({"prompt": [1], "temperature": -1}, 400), ({"prompt": [1], "top_p": 0}, 400),
+                       ({"prompt": [1], "logprobs": 5}, 400)]:
         r = c.post("/v1/completions", json=body)
         assert r.status_code == code, (body, r.text)
         err = r.json()["error"]
         assert set(err) >= {"message", "type", "code"}
     assert c.post("/v1/completions", content=b"{not json").status_code == 400
+    th.shutdown()
+
+
+def test_sampling_parameters_are_accepted():
+    th, c, _, _ = make()
+    th.ready.wait(10)
+    r = c.post("/v1/completions", json={"prompt": [1, 2], "max_tokens": 3, "temperature": 0.8, "top_k": 20,
+                                        "top_p": 0.9, "seed": 11})
+    assert r.status_code == 200 and r.json()["usage"]["completion_tokens"] == 3
+    s = th.engine.runner.last_sampling
+    assert s is not None and s["seeds"].tolist() == [11] and s["top_k"].tolist() == [20]
     th.shutdown()
 
 

@@ -75,6 +75,227 @@ __global__ __launch_bounds__(kArgmaxThreads) void argmax_kernel(int64_t* __restr
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Random sampling: temperature, top-k (k <= 1024), top-p, one 1024-thread
+// workgroup per row.  Every arithmetic step is plain fp32 in a fixed order
+// (contraction off, polynomial exp, sequential cumulative sum), so the result is
+// a pure function of (logits, parameters, seed, step) and equals the CPU
+// restatement bit for bit.
+//   1. radix select (4 passes of 8 bits over order-preserving keys, LDS
+//      histogram) finds the k-th largest key T
+//   2. candidates = keys > T, plus the lowest-index keys == T (ordered placement
+//      with wave ballots over wave-contiguous ranges)
+//   3. bitonic sort in LDS by (key desc, index asc)
+//   4. w_i = exp((l_i - l_0) / t); sequential cumulative sum; top-p cut; one
+//      uniform from a counter hash of (seed, step) picks the token by inverse CDF
+// The row (vocab * 2 or 4 bytes) is read 6 times, L2-resident after the first.
+// ---------------------------------------------------------------------------
+constexpr int kSampleThreads = 1024;
+constexpr int kSampleKMax = 1024;
+
+__device__ __forceinline__ uint32_t sample_key(float v) {
+  if (v != v) return 0u;
+  uint32_t u = (v == 0.0f) ? 0u : __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float key_to_logit(uint32_t k) {
+  if (k == 0u) return -INFINITY;
+  const uint32_t u = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+  return __uint_as_float(u);
+}
+
+template <int LDT>
+__device__ __forceinline__ float load_logit(const void* row, int i) {
+  if (LDT == MI355_F32) return static_cast<const float*>(row)[i];
+  const uint16_t raw = static_cast<const uint16_t*>(row)[i];
+  return LDT == MI355_BF16 ? BF16::to_f(raw) : F16::to_f(raw);
+}
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+
+__device__ __forceinline__ float sample_uniform(uint64_t seed, uint64_t step) {
+  uint32_t h = mix32(static_cast<uint32_t>(seed) ^ 0x9E3779B9u);
+  h = mix32(h ^ static_cast<uint32_t>(seed >> 32));
+  h = mix32(h ^ static_cast<uint32_t>(step));
+  h = mix32(h ^ static_cast<uint32_t>(step >> 32) ^ 0x85EBCA6Bu);
+  return (static_cast<float>(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+// exp(z), z <= 0: 2^n * poly(f) with y = z*log2(e), n = floor(y), f = y - n.
+__device__ __forceinline__ float exp_det(float z) {
+#pragma clang fp contract(off)
+  const float y = z * 1.4426950408889634f;
+  const float n = floorf(y);
+  if (!(n >= -126.0f)) return 0.0f;
+  const float f = y - n;
+  const float c[8] = {1.0f, 0.6931471805599453f, 0.2402265069591007f, 0.05550410866482158f,
+                      0.009618129107628477f, 0.0013333558146428443f, 0.00015403530393381608f,
+                      1.5252733804059840e-05f};
+  float r = c[7];
+#pragma unroll
+  for (int i = 6; i >= 0; --i) {
+    r = r * f;
+    r = r + c[i];
+  }
+  const int ni = static_cast<int>(n);
+  const float scale = __uint_as_float(static_cast<uint32_t>(ni + 127) << 23);
+  return r * scale;
+}
+
+template <int LDT>
+__global__ __launch_bounds__(kSampleThreads) void sample_kernel(
+    int64_t* __restrict__ out, const void* __restrict__ logits, int64_t stride, int vocab,
+    const float* __restrict__ temperature, const int32_t* __restrict__ top_k, const float* __restrict__ top_p,
+    const int64_t* __restrict__ seeds, const int64_t* __restrict__ steps) {
+#pragma clang fp contract(off)
+  const int row = blockIdx.x;
+  const float temp = temperature[row];
+  if (!(temp > 0.0f)) return;  // greedy rows keep the argmax written before
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const void* base = LDT == MI355_F32
+                         ? static_cast<const void*>(static_cast<const float*>(logits) + row * stride)
+                         : static_cast<const void*>(static_cast<const uint16_t*>(logits) + row * stride);
+  int k = top_k[row];
+  k = (k > 0 && k <= kSampleKMax) ? k : kSampleKMax;
+  k = min(k, vocab);
+
+  __shared__ int hist[256];
+  __shared__ unsigned long long comp[kSampleKMax];
+  __shared__ float csum[kSampleKMax];
+  __shared__ int sh_digit, sh_need, sh_gt;
+  __shared__ int eq_base[kSampleThreads / 64 + 1];
+
+  // ---- 1. radix select of the k-th largest key
+  uint32_t prefix = 0u, mask = 0u;
+  int need = k;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < vocab; i += kSampleThreads) {
+      const uint32_t key = sample_key(load_logit<LDT>(base, i));
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int rem = need, d = 255;
+      for (; d > 0; --d) {
+        if (hist[d] >= rem) break;
+        rem -= hist[d];
+      }
+      sh_digit = d;
+      sh_need = rem;
+    }
+    __syncthreads();
+    prefix |= static_cast<uint32_t>(sh_digit) << shift;
+    mask |= 255u << shift;
+    need = sh_need;
+    __syncthreads();
+  }
+  const uint32_t T = prefix;  // `need` keys equal to T are taken, lowest indices first
+  const int n_gt = k - need;
+
+  // ---- 2. gather: wave w owns the contiguous index range [w*R, (w+1)*R)
+  const int R = ((vocab + (kSampleThreads / 64) - 1) / (kSampleThreads / 64) + 63) / 64 * 64;
+  const int r0 = wave * R, r1 = min(vocab, r0 + R);
+  int eq_count = 0;
+  for (int i0 = r0; i0 < r1; i0 += 64) {
+    const int i = i0 + lane;
+    const bool eq = i < r1 && sample_key(load_logit<LDT>(base, i)) == T;
+    eq_count += __popcll(__ballot(eq));
+  }
+  if (tid == 0) sh_gt = 0;
+  for (int i = tid; i < kSampleKMax; i += kSampleThreads) comp[i] = 0ull;
+  if (lane == 0) eq_base[wave + 1] = eq_count;
+  __syncthreads();
+  if (tid == 0) {
+    eq_base[0] = 0;
+    for (int w = 0; w < kSampleThreads / 64; ++w) eq_base[w + 1] += eq_base[w];
+  }
+  __syncthreads();
+  int eq_run = eq_base[wave];
+  for (int i0 = r0; i0 < r1; i0 += 64) {
+    const int i = i0 + lane;
+    uint32_t key = 0u;
+    bool gt = false, eq = false;
+    if (i < r1) {
+      key = sample_key(load_logit<LDT>(base, i));
+      gt = key > T;
+      eq = key == T;
+    }
+    const unsigned long long eqm = __ballot(eq);
+    const unsigned long long cv = (static_cast<unsigned long long>(key) << 32) |
+                                  static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<uint32_t>(i));
+    if (gt) comp[atomicAdd(&sh_gt, 1)] = cv;
+    if (eq) {
+      const int rank = eq_run + __popcll(eqm & ((1ull << lane) - 1ull));
+      if (rank < need) comp[n_gt + rank] = cv;
+    }
+    eq_run += __popcll(eqm);
+  }
+  __syncthreads();
+
+  // ---- 3. bitonic sort, descending
+  for (int size = 2; size <= kSampleKMax; size <<= 1) {
+    for (int j = size >> 1; j > 0; j >>= 1) {
+      const int p = tid ^ j;
+      if (p > tid) {
+        const unsigned long long a = comp[tid], b = comp[p];
+        const bool desc = (tid & size) == 0;
+        if (desc ? (a < b) : (a > b)) {
+          comp[tid] = b;
+          comp[p] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- 4. weights, sequential cumulative sum, top-p cut, inverse-CDF pick
+  const float l0 = key_to_logit(static_cast<uint32_t>(comp[0] >> 32));
+  if (tid < k) {
+    const float li = key_to_logit(static_cast<uint32_t>(comp[tid] >> 32));
+    float z = (li - l0) / temp;
+    if (z != z) z = -INFINITY;
+    csum[tid] = exp_det(z);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float acc = 0.0f;
+    for (int i = 0; i < k; ++i) {
+      acc = acc + csum[i];
+      csum[i] = acc;
+    }
+    int keep = k;
+    const float tp = top_p[row];
+    if (tp < 1.0f) {
+      const float thr = tp * csum[k - 1];
+      for (int i = 0; i < k; ++i)
+        if (csum[i] >= thr) {
+          keep = i + 1;
+          break;
+        }
+    }
+    const float target = sample_uniform(static_cast<uint64_t>(seeds[row]), static_cast<uint64_t>(steps[row])) *
+                         csum[keep - 1];
+    int pick = keep - 1;
+    for (int i = 0; i < keep; ++i)
+      if (csum[i] > target) {
+        pick = i;
+        break;
+      }
+    out[row] = static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(comp[pick] & 0xFFFFFFFFull));
+  }
+}
+
 }  // namespace mi355
 
 extern "C" int32_t mi355_argmax(int64_t* out_ids, const void* logits, int64_t logits_stride,
@@ -98,5 +319,29 @@ extern "C" int32_t mi355_argmax(int64_t* out_ids, const void* logits, int64_t lo
     hipLaunchKernelGGL((argmax_kernel<MI355_BF16>), grid, block, 0, s, out_ids, logits, logits_stride, vocab);
   else
     hipLaunchKernelGGL((argmax_kernel<MI355_F16>), grid, block, 0, s, out_ids, logits, logits_stride, vocab);
+  return check_launch(name);
+}
+
+extern "C" int32_t mi355_sample_topk_topp(int64_t* out_ids, const void* logits, int64_t logits_stride,
+                                          int32_t num_rows, int32_t vocab, int32_t logits_dtype,
+                                          const float* temperature, const int32_t* top_k, const float* top_p,
+                                          const int64_t* seeds, const int64_t* steps, void* stream) {
+  using namespace mi355;
+  const char* name = "mi355_sample_topk_topp";
+  MI355_REQUIRE(temperature && top_k && top_p && seeds && steps, MI355_ERR_INVALID, "%s: null pointer", name);
+  // greedy token for every row first; rows with temperature > 0 are then re-drawn
+  const int32_t rc = mi355_argmax(out_ids, logits, logits_stride, num_rows, vocab, logits_dtype, stream);
+  if (rc != MI355_OK || num_rows == 0) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid(num_rows), block(kSampleThreads);
+  if (logits_dtype == MI355_F32)
+    hipLaunchKernelGGL((sample_kernel<MI355_F32>), grid, block, 0, s, out_ids, logits, logits_stride, vocab,
+                       temperature, top_k, top_p, seeds, steps);
+  else if (logits_dtype == MI355_BF16)
+    hipLaunchKernelGGL((sample_kernel<MI355_BF16>), grid, block, 0, s, out_ids, logits, logits_stride, vocab,
+                       temperature, top_k, top_p, seeds, steps);
+  else
+    hipLaunchKernelGGL((sample_kernel<MI355_F16>), grid, block, 0, s, out_ids, logits, logits_stride, vocab,
+                       temperature, top_k, top_p, seeds, steps);
   return check_launch(name);
 }

@@ -48,6 +48,7 @@ def _load() -> ctypes.CDLL:
                                            F, I32, P]),
         "mi355_silu_and_mul": (I32, [P, P, I64, I64, I32, I32, P]),
         "mi355_argmax": (I32, [P, P, I64, I32, I32, I32, P]),
+        "mi355_sample_topk_topp": (I32, [P, P, I64, I32, I32, I32, P, P, P, P, P, P]),
         "mi355_linear_decode": (I32, [P, I64, P, I64, P, P, I32, I32, I32, I32, I32, P]),
     }
     for name, (res, args) in sigs.items():
@@ -63,7 +64,7 @@ lib = _load()
 EXPORTS = ("mi355_abi_version", "mi355_last_error", "mi355_target_arch", "mi355_rms_norm",
            "mi355_fused_add_rms_norm", "mi355_rope_kv_write", "mi355_paged_attn_decode_workspace",
            "mi355_paged_attn_decode", "mi355_paged_attn_prefill", "mi355_silu_and_mul", "mi355_argmax",
-           "mi355_linear_decode")
+           "mi355_linear_decode", "mi355_sample_topk_topp")
 
 
 def check(status: int) -> None:

@@ -63,6 +63,7 @@ class Sequence:
     finish_time: Optional[float] = None
     finish_reason: Optional[str] = None
     num_preemptions: int = 0
+    seed: int = 0                    # sampling seed (request's, or drawn by the engine)
 
     @property
     def all_ids(self) -> List[int]:
@@ -191,8 +192,12 @@ class Scheduler:
 class LLMEngine:
     """Single-GPU (or one TP rank's) engine.  `runner` is a ModelRunner."""
 
+    supports_random_sampling = True
+
     def __init__(self, runner, max_num_seqs: int, max_num_batched_tokens: int, max_model_len: int,
-                 eos_token_ids=None):
+                 eos_token_ids=None, seed: int = 0):
+        import random
+        self._rng = random.Random(seed)          # same stream on every TP rank
         self.runner = runner
         self.device = runner.device
         self.max_model_len = max_model_len
@@ -222,6 +227,7 @@ class LLMEngine:
         if bad:
             raise ValueError(f"token id {bad[0]} outside the vocabulary (size {self.runner.V})")
         seq = Sequence(request_id, list(prompt_token_ids), params)
+        seq.seed = params.seed if params.seed is not None else self._rng.getrandbits(62)
         if arrival_time is not None:
             seq.arrival_time = arrival_time
         self.seqs[request_id] = seq
@@ -255,6 +261,19 @@ class LLMEngine:
             self.sched.release(seq)
             self.seqs.pop(seq.request_id, None)
 
+    @staticmethod
+    def _sampling_arrays(seqs: List[Sequence]) -> Optional[dict]:
+        """Per-row sampling parameters, or None when every row is greedy."""
+        if all(s.params.greedy for s in seqs):
+            return None
+        return {
+            "temperature": np.asarray([s.params.temperature for s in seqs], dtype=np.float32),
+            "top_k": np.asarray([s.params.top_k for s in seqs], dtype=np.int32),
+            "top_p": np.asarray([s.params.top_p for s in seqs], dtype=np.float32),
+            "seeds": np.asarray([s.seed & 0x7FFFFFFFFFFFFFFF for s in seqs], dtype=np.int64),
+            "steps": np.asarray([len(s.output_ids) for s in seqs], dtype=np.int64),
+        }
+
     def _output(self, seq: Sequence, new: List[int]) -> RequestOutput:
         return RequestOutput(seq.request_id, new, seq.finished, seq.finish_reason, len(seq.prompt_ids),
                              len(seq.output_ids), seq.arrival_time, seq.first_token_time, seq.finish_time)
@@ -275,7 +294,8 @@ class LLMEngine:
             bt[i, : len(seq.blocks)] = seq.blocks
         nxt = self.runner.run_prefill(np.concatenate(toks), np.concatenate(pos), np.concatenate(slots), bt,
                                       np.asarray(cu, dtype=np.int32), np.asarray(ctx, dtype=np.int32),
-                                      max(n for _, _, n in chunks))
+                                      max(n for _, _, n in chunks),
+                                      sampling=self._sampling_arrays([c[0] for c in chunks]))
         now = time.perf_counter()
         outs = []
         self.stats["prefill_steps"] += 1
@@ -302,7 +322,7 @@ class LLMEngine:
             n64[2 * B + i] = seq.blocks[p // BLOCK_SIZE] * BLOCK_SIZE + p % BLOCK_SIZE
             n32[i] = p + 1
             bt[i, : len(seq.blocks)] = seq.blocks
-        toks = r.run_decode(n)
+        toks = r.run_decode(n, sampling=self._sampling_arrays(seqs))
         now = time.perf_counter()
         self.stats["decode_steps"] += 1
         self.stats["decode_tokens"] += n

@@ -93,7 +93,8 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
                          decode_splits=decode_splits)
     eos = cfg.eos_token_id
     eos = [] if eos is None else (list(eos) if isinstance(eos, (list, tuple)) else [eos])
-    return LLMEngine(runner, args.max_num_seqs, max(args.max_num_batched_tokens, 1), max_model_len, eos)
+    return LLMEngine(runner, args.max_num_seqs, max(args.max_num_batched_tokens, 1), max_model_len, eos,
+                     seed=args.seed)
 
 
 class LLM:

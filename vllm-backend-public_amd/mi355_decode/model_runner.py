@@ -221,27 +221,41 @@ class ModelRunner:
         """numpy views of the pinned staging buffers, laid out like in64 / in32."""
         return self.h64.numpy(), self.h32.numpy()
 
-    def run_decode(self, batch: int):
+    def _sample(self, logits: torch.Tensor, sampling: dict, out: torch.Tensor) -> None:
+        """Re-draw the rows that asked for random sampling (greedy rows keep argmax)."""
+        dev = self.device
+        t = lambda a, dt: torch.from_numpy(a).to(dev, dtype=dt, non_blocking=True)  # noqa: E731
+        ops.sample(logits, t(sampling["temperature"], torch.float32), t(sampling["top_k"], torch.int32),
+                   t(sampling["top_p"], torch.float32), t(sampling["seeds"], torch.int64),
+                   t(sampling["steps"], torch.int64), out=out)
+
+    def run_decode(self, batch: int, sampling: Optional[dict] = None):
         """Host-facing decode step: ships the staged inputs, replays the step and
-        returns the sampled token ids as a Python list (one stream sync)."""
+        returns the sampled token ids as a Python list (one stream sync).
+        `sampling` (numpy arrays temperature/top_k/top_p/seeds/steps, one entry per
+        row) is given only when some row is not greedy."""
         self.in64.copy_(self.h64, non_blocking=True)
         self.in32.copy_(self.h32, non_blocking=True)
         nxt = self.decode(batch)
+        if sampling is not None:
+            self._sample(self.logits[:batch], sampling, nxt)
         self.h_next[:batch].copy_(nxt, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         return self.h_next[:batch].tolist()
 
     def run_prefill(self, token_ids, positions, slot_mapping, block_tables, cu_seqlens, context_lens,
-                    max_q_len: int):
+                    max_q_len: int, sampling: Optional[dict] = None):
         """Host-facing prefill step over numpy inputs; returns next-token ids (list)."""
         dev = self.device
 
         def t(a, dt):
             return torch.from_numpy(a).to(dev, dtype=dt, non_blocking=True)
 
-        nxt, _ = self.prefill(t(token_ids, torch.int64), t(positions, torch.int64), t(slot_mapping, torch.int64),
-                              t(block_tables, torch.int32), t(cu_seqlens, torch.int32),
-                              t(context_lens, torch.int32), int(max_q_len), want_logits=False)
+        nxt, logits = self.prefill(t(token_ids, torch.int64), t(positions, torch.int64), t(slot_mapping, torch.int64),
+                                   t(block_tables, torch.int32), t(cu_seqlens, torch.int32),
+                                   t(context_lens, torch.int32), int(max_q_len), want_logits=sampling is not None)
+        if sampling is not None:
+            self._sample(logits, sampling, nxt)
         return nxt.cpu().tolist()
 
     # ------------------------------------------------------------------ #

@@ -211,3 +211,24 @@ def linear_decode(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | No
     check(lib.mi355_linear_decode(out.data_ptr(), _rows(out, "out"), x.data_ptr(), _rows(x, "x"), weight.data_ptr(),
                                   bias.data_ptr() if bias is not None else 0, M, N, K, int(k_slices), dt, _stream()))
     return out
+
+
+def sample(logits: torch.Tensor, temperature: torch.Tensor, top_k: torch.Tensor, top_p: torch.Tensor,
+           seeds: torch.Tensor, steps: torch.Tensor, out: torch.Tensor | None = None):
+    """Per-row sampling (greedy where temperature <= 0).  temperature/top_p float32 [B], top_k int32 [B],
+    seeds/steps int64 [B], all on the device."""
+    _dev(logits, "logits")
+    if logits.dtype not in _DT:
+        raise TypeError(f"logits dtype {logits.dtype} not supported")
+    B, V = logits.shape
+    for t, n, dt in ((temperature, "temperature", torch.float32), (top_k, "top_k", torch.int32),
+                     (top_p, "top_p", torch.float32), (seeds, "seeds", torch.int64), (steps, "steps", torch.int64)):
+        _dev(t, n)
+        if t.dtype != dt or t.numel() != B or not t.is_contiguous():
+            raise ValueError(f"{n} must be contiguous {dt} [num_rows]")
+    if out is None:
+        out = torch.empty(B, dtype=torch.int64, device=logits.device)
+    check(lib.mi355_sample_topk_topp(out.data_ptr(), logits.data_ptr(), _rows(logits, "logits"), B, V,
+                                     _DT[logits.dtype], temperature.data_ptr(), top_k.data_ptr(), top_p.data_ptr(),
+                                     seeds.data_ptr(), steps.data_ptr(), _stream()))
+    return out
