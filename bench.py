@@ -204,6 +204,18 @@ def cpu_baseline(cfg, batch, ctx_len, sample_layers=2, steps=2):
             "stock_vllm_cpu": "unavailable offline (vllm is not installed; nothing can be fetched)"}
 
 
+def pmc_traffic(prefix):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (or None)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")) as f:
+            for name, rec in json.load(f)["kernels"].items():
+                if name.startswith(prefix):
+                    return rec["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     a = parse()
     import torch
@@ -317,7 +329,9 @@ def main():
         dom = kern["gemm_gate_up"]
         result["roofline"] = {"bound": "hbm", "kernel": "gate/up projection GEMM (M=%d, N=%d, K=%d)" % (batch, 2 * cfg.intermediate_size, cfg.hidden_size),
                               "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
-                              "traffic": None, "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"]}
+                              "traffic": pmc_traffic("gemm_gate_up"), "traffic_source": "profiles/r01_b_pmc_traffic.json "
+                              "(rocprofv3 PMC passes of this workload; not re-measured in this run)",
+                              "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"]}
     if world > 1:
         dist.barrier()
     if rank == 0:

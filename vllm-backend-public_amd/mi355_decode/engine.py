@@ -50,7 +50,7 @@ class BlockAllocator:
         self._free.extend(reversed(blocks))
 
 
-@dataclass
+@dataclass(eq=False)          # identity semantics: sequences live in scheduler lists
 class Sequence:
     request_id: str
     prompt_ids: List[int]
