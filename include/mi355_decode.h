@@ -219,6 +219,78 @@ int32_t mi355_linear_decode(void* y, int64_t y_stride, const void* x,
                             const void* bias, int32_t M, int32_t N, int32_t K,
                             int32_t k_slices, int32_t dtype, void* stream);
 
+/*
+ * Fragment-tiled weights for mi355_linear_tiled.  A row-major [N, K] matrix is
+ * re-laid once (at model load) into 1 KB blocks of 16 rows x 32 k stored in the
+ * register order of the MFMA operand, blocks ordered [tile][k-step]; rows are
+ * zero-padded to a multiple of 16.  mi355_tiled_weight_elems gives the element
+ * count of the destination.  With interleave_halves != 0 the 16-row tiles
+ * alternate between the first and the second half of the rows (gate / up of a
+ * fused SwiGLU projection), which lets the GEMM epilogue apply the gate.
+ */
+int64_t mi355_tiled_weight_elems(int32_t N, int32_t K);
+int32_t mi355_tile_weights(void* dst, const void* src, int32_t N, int32_t K,
+                           int32_t interleave_halves, void* stream);
+
+/*
+ * Decode-time linear layer on fragment-tiled weights, M <= 32:
+ * y[M, N] = x[M, K] . W[N, K]^T.  Every weight load is 1 KB of contiguous memory
+ * and each wave streams one 16-row tile of W; x is staged through LDS once per
+ * workgroup.  tiles_per_wg = 4 or 8 tiles (= waves) per workgroup with 1024-wide
+ * x slices (K % 1024 == 0), or 104 / 108 for the same with 512-wide slices
+ * (K % 512 == 0, two workgroups per CU); k_groups splits K over workgroups and
+ * must divide the slice count.
+ *   epilogue 0: y = round(sum + bias)                       (k_groups == 1)
+ *   epilogue 1: weights tiled with interleave_halves; y[M, N/2] =
+ *               round(round(silu(round(gate))) * round(up))  (k_groups == 1)
+ *   epilogue 2: fp32 partial sums to partial[k_groups][M][N]; the consumers
+ *               (mi355_fused_add_rms_norm_partial, mi355_rope_kv_write_partial)
+ *               add the slabs in order, so results do not depend on scheduling.
+ * Same role as mi355_linear_decode (the engine's decode GEMMs, --max-num-seqs,
+ * vllm_templates.py:53) with the weight layout chosen for this chip.
+ */
+int32_t mi355_linear_tiled(void* y, int64_t y_stride, void* partial,
+                           const void* x, int64_t x_stride, const void* w_tiled,
+                           const void* bias, int32_t M, int32_t N, int32_t K,
+                           int32_t tiles_per_wg, int32_t k_groups,
+                           int32_t epilogue, int32_t dtype, void* stream);
+
+/*
+ * mi355_fused_add_rms_norm whose x is the output of a K-split linear layer still
+ * in partial-sum form:  x = round(partial[0] + ... + partial[num_slabs-1] + bias)
+ * (fp32, slab order), then residual = round(x + residual); out =
+ * rms_norm(residual).  partial is fp32 [num_slabs][num_tokens][hidden] with
+ * slab_stride elements between slabs; bias [hidden] may be NULL.  Finishes the
+ * o_proj / down_proj GEMM, the residual add and the following norm in one pass
+ * (same engine operators as mi355_fused_add_rms_norm).
+ */
+int32_t mi355_fused_add_rms_norm_partial(void* out, const float* partial,
+                                         int32_t num_slabs, int64_t slab_stride,
+                                         const void* bias, void* residual,
+                                         const void* weight, int64_t num_tokens,
+                                         int32_t hidden, int64_t out_stride,
+                                         int64_t residual_stride, float eps,
+                                         int32_t dtype, void* stream);
+
+/*
+ * mi355_rope_kv_write whose packed QKV rows are still in partial-sum form:
+ * qkv = round(partial[0] + ... + partial[num_slabs-1] + bias) is formed first
+ * (fp32, slab order; partial fp32 [num_slabs][num_tokens][width], width =
+ * (num_heads + 2*num_kv_heads) * head_dim, bias [width] or NULL), then q and k
+ * are rotated, and q, k, v are written to `qkv` (16-bit rows) and k, v to the
+ * cache exactly as mi355_rope_kv_write leaves them.
+ */
+int32_t mi355_rope_kv_write_partial(void* qkv, int64_t qkv_stride,
+                                    const float* partial, int32_t num_slabs,
+                                    int64_t slab_stride, const void* bias,
+                                    const int64_t* positions, const void* cos_sin,
+                                    int32_t max_position,
+                                    const int64_t* slot_mapping, void* k_cache,
+                                    void* v_cache, int32_t num_blocks,
+                                    int64_t num_tokens, int32_t num_heads,
+                                    int32_t num_kv_heads, int32_t head_dim,
+                                    int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

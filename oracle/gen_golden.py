@@ -150,13 +150,15 @@ def gen_ops():
 
 
 # --------------------------------------------------------------------------- #
-def gen_tiny():
+def gen_tiny(only=None):
     import torch
     import transformers
 
     G = 24
     lengths = [5, 16, 17, 33]
     for name in TINY:
+        if only and name not in only:
+            continue
         arch, cfg, w = make_weights(name)
         cfg_cls = {"LlamaForCausalLM": transformers.LlamaConfig,
                    "Qwen2ForCausalLM": transformers.Qwen2Config}[arch]
@@ -319,5 +321,8 @@ if __name__ == "__main__":
         gen_ops()
     if "tiny" in which:
         gen_tiny()
+    only = [a.split("=", 1)[1] for a in which if a.startswith("tiny=")]   # e.g. tiny=qwen2_d128
+    if only:
+        gen_tiny(only)
     if "harness" in which:
         gen_harness()

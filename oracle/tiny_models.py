@@ -32,6 +32,13 @@ TINY = {
         num_attention_heads=7, num_key_value_heads=1, head_dim=64, rope_theta=1000000.0,
         rms_norm_eps=1e-6, max_position_embeddings=512, tie_word_embeddings=False,
         attention_bias=True), 13),
+    # Qwen2 with every matrix wide enough (K a multiple of 512) for the fragment-tiled
+    # decode GEMMs: bias on q/k/v through the K-split path, group 2, head_dim 128
+    "qwen2_d128": ("Qwen2ForCausalLM", dict(
+        vocab_size=448, hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
+        num_attention_heads=4, num_key_value_heads=2, head_dim=128, rope_theta=1000000.0,
+        rms_norm_eps=1e-6, max_position_embeddings=512, tie_word_embeddings=False,
+        attention_bias=True), 14),
 }
 
 

@@ -251,3 +251,20 @@ def test_random_sampling_through_the_engine():
     # temperature -> greedy limit: top_k = 1 is argmax whatever the seed
     g1 = gen(300, temperature=1.0, top_k=1, top_p=1.0)
     np.testing.assert_array_equal(g1, engine_generate(eng, prompts, 12))
+
+
+@pytest.mark.parametrize("name", ["llama_d128", "qwen2_d128"])
+def test_tiled_and_library_gemm_paths_both_match_oracle(name, monkeypatch):
+    """The decode step on fragment-tiled weights (K-split GEMMs feeding the norm and
+    rotary kernels in partial-sum form, SwiGLU in the GEMM epilogue) and the step on
+    library GEMMs are two implementations of the same arithmetic: each is held to the
+    oracle, and the tiled one must really be the one that ran by default."""
+    prompts = make_prompts(name, len(LENGTHS), LENGTHS)
+    eng_t, cfg, w = build(name, "bfloat16")
+    assert eng_t.runner.tiled is not None, "tiled decode path not active for an eligible model"
+    got_t = _oracle_checked(eng_t, cfg, w, prompts, 16, f"{name} tiled")
+    monkeypatch.setenv("MI355_TILED_LINEARS", "0")
+    eng_l, _, _ = build(name, "bfloat16")
+    assert eng_l.runner.tiled is None
+    got_l = _oracle_checked(eng_l, cfg, w, prompts, 16, f"{name} library GEMMs")
+    assert (got_t[:, 0] == got_l[:, 0]).all()          # first token comes from the shared prefill path

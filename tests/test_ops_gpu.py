@@ -443,3 +443,141 @@ def test_sample_distribution(ops):
     assert set(out) <= set(top)
     freq = np.array([(out == t).mean() for t in top])
     assert np.abs(freq - p).max() < 4 * np.sqrt(p.max() / n) + 0.01
+
+
+# --------------------------------------------------------------------------- #
+# decode-time linear layer on fragment-tiled weights
+# --------------------------------------------------------------------------- #
+def _linear_tol(ref64, x, w, K, dtype):
+    return ULP[dtype] * np.abs(ref64) * 1.01 + 1e-5 * np.sqrt(K) * np.abs(x).max() * np.abs(w).max() + 2 * SUBNORMAL_STEP[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,N,K,bias", [(1, 64, 1024, False), (5, 320, 1024, True), (32, 4096, 4096, False),
+                                        (32, 6144, 4096, True), (17, 1000, 2048, True), (32, 28672, 4096, False),
+                                        (16, 100, 3072, False)])
+@pytest.mark.parametrize("tiles", [0, 4, 8, 104, 108])
+def test_linear_tiled_store(ops, dtype, M, N, K, bias, tiles):
+    rng = rng_for("tiled", dtype, M, N, K)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (N, K), dtype, 0.05)
+    b = grid(rng, (N,), dtype) if bias else None
+    wt = ops.tile_weights(dev(w, dtype))
+    y = host(ops.linear_tiled(dev(x, dtype), wt, N, dev(b, dtype) if bias else None, tiles_per_wg=tiles))
+    ref64 = x.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
+    err = np.abs(y - ref64)
+    assert (err <= _linear_tol(ref64, x, w, K, dtype)).all(), f"max err {err.max()}"
+    assert (y != R.linear(x, w, b, dtype)).mean() <= 0.02
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,N,K,groups", [(32, 4096, 4096, 4), (32, 4096, 14336, 7), (9, 512, 2048, 2), (32, 256, 1024, 1)])
+def test_linear_tiled_partial_slabs(ops, dtype, M, N, K, groups):
+    rng = rng_for("tiled-partial", dtype, M, N, K)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (N, K), dtype, 0.05)
+    wt = ops.tile_weights(dev(w, dtype))
+    part = ops.linear_tiled(dev(x, dtype), wt, N, k_groups=groups, epilogue=ops.EPI_PARTIAL).cpu().numpy()
+    part2 = ops.linear_tiled(dev(x, dtype), wt, N, k_groups=groups, epilogue=ops.EPI_PARTIAL, tiles_per_wg=104).cpu().numpy()
+    np.testing.assert_array_equal(part, part2)             # geometry does not change the sums
+    assert part.shape == (groups, M, N)
+    kg = K // groups
+    for g in range(groups):                      # every slab is the product over its own K range
+        ref = x[:, g * kg:(g + 1) * kg].astype(np.float64) @ w[:, g * kg:(g + 1) * kg].astype(np.float64).T
+        np.testing.assert_allclose(part[g], ref, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,F,K", [(32, 14336, 4096), (7, 512, 1024), (32, 1536, 1024), (1, 64, 2048)])
+def test_linear_tiled_swiglu_epilogue(ops, dtype, M, F, K):
+    """gate/up projection with the SwiGLU gate fused == silu_and_mul(linear(x, [gate; up]))."""
+    rng = rng_for("tiled-silu", dtype, M, F, K)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (2 * F, K), dtype, 0.05)
+    wt = ops.tile_weights(dev(w, dtype), interleave_halves=True)
+    y = host(ops.linear_tiled(dev(x, dtype), wt, 2 * F, epilogue=ops.EPI_SILU_MUL))
+    ref = R.silu_and_mul(R.linear(x, w, None, dtype), dtype)
+    # the GEMM sums may round differently on a few elements (other accumulation order);
+    # each such flip moves the gated product by at most a few ulps
+    diff = np.abs(y - ref)
+    assert (diff <= 4 * ULP[dtype] * np.abs(ref) + 4 * ULP[dtype] * 1e-2).all(), f"max diff {diff.max()}"
+    assert (diff > 0).mean() <= 0.03
+    # and against the unfused HIP path on the same machine
+    gu = ops.linear_tiled(dev(x, dtype), ops.tile_weights(dev(w, dtype)), 2 * F)
+    np.testing.assert_array_equal(y, host(ops.silu_and_mul(gu)))
+
+
+def _slab_sum(part, bias, dtype):
+    """round(slab_0 + slab_1 + ... + bias) in fp32, slab order: what the consumers of partial sums form."""
+    acc = np.zeros(part.shape[1:], np.float32)
+    for s in range(part.shape[0]):
+        acc = acc + part[s]
+    if bias is not None:
+        acc = acc + bias.astype(np.float32)
+    return R.round_to(acc, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("T,H,S,bias", [(32, 4096, 4, False), (5, 448, 1, True), (3, 8192, 7, False),
+                                        (2, 16384, 2, True), (1, 256, 8, False)])
+def test_fused_add_rms_norm_partial(ops, dtype, T, H, S, bias):
+    rng = rng_for("rms-partial", dtype, T, H, S)
+    part = (rng.standard_normal((S, T, H)) * 0.7).astype(np.float32)
+    b = grid(rng, (H,), dtype) if bias else None
+    w, res = R.round_to(1 + 0.1 * rng.standard_normal(H), dtype), grid(rng, (T, H), dtype)
+    x = _slab_sum(part, b, dtype)
+    y_ref, z_ref = R.fused_add_rms_norm(x, res, w, 1e-5, dtype)
+    rd = dev(res, dtype)
+    out = torch.empty(T, H, dtype=DT[dtype], device="cuda")
+    ops.fused_add_rms_norm_partial(torch.from_numpy(part).cuda(), S, rd, dev(w, dtype), 1e-5, out,
+                                   bias=dev(b, dtype) if bias else None)
+    np.testing.assert_array_equal(host(rd), z_ref)            # slab sum + residual add: bit-exact
+    assert_ulp_close(host(out), y_ref, dtype, 0.005)
+    # and identical to the two-kernel path on the same machine
+    rd2 = dev(res, dtype)
+    out2 = ops.fused_add_rms_norm(dev(x, dtype), rd2, dev(w, dtype), 1e-5)
+    np.testing.assert_array_equal(host(out), host(out2))
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("nh,kvh,d,S,bias", [(4, 2, 64, 2, False), (32, 8, 128, 2, False), (28, 4, 128, 4, True),
+                                             (7, 1, 64, 1, True)])
+def test_rope_kv_write_partial(ops, dtype, nh, kvh, d, S, bias):
+    rng = rng_for("rope-partial", dtype, nh, kvh, d, S)
+    T, nblk, max_pos = 29, 10, 512
+    width = (nh + 2 * kvh) * d
+    table = R.rope_cos_sin_table(max_pos, d, 5e5, dtype)
+    part = (rng.standard_normal((S, T, width)) * 0.6).astype(np.float32)
+    b = grid(rng, (width,), dtype) if bias else None
+    qkv = _slab_sum(part, b, dtype)
+    pos = rng.integers(0, max_pos, T).astype(np.int64)
+    slots = rng.permutation(nblk * 16)[:T].astype(np.int64)
+    slots[5] = -1
+    kc_ref = np.zeros((nblk, kvh, 16, d), np.float32)
+    vc_ref = np.zeros((nblk, kvh, d, 16), np.float32)
+    ref = R.rope_kv_write(qkv, pos, table, slots, kc_ref, vc_ref, nh, kvh, d, dtype)
+
+    kc, vc = make_cache(nblk, kvh, d, dtype)
+    qd = torch.full((T, width), 7.0, dtype=DT[dtype], device="cuda")     # every element must be overwritten
+    ops.rope_kv_write(qd, torch.from_numpy(pos).cuda(), dev(table, dtype), torch.from_numpy(slots).cuda(),
+                      kc, vc, nh, kvh, d, partial=torch.from_numpy(part).cuda(), num_slabs=S,
+                      bias=dev(b, dtype) if bias else None)
+    np.testing.assert_array_equal(host(qd), ref)              # bit-exact, v rows included
+    np.testing.assert_array_equal(host(kc), kc_ref)
+    np.testing.assert_array_equal(host(vc), vc_ref)
+
+
+def test_tiled_decode_chain_matches_plain_chain(ops):
+    """o_proj in partial-sum form + fused slab-sum/add/norm == linear -> fused_add_rms_norm."""
+    dtype = "bfloat16"
+    rng = rng_for("tiled-chain")
+    M, N, K, G = 32, 4096, 4096, 4
+    x, w = grid(rng, (M, K), dtype), grid(rng, (N, K), dtype, 0.02)
+    res, nw = grid(rng, (M, N), dtype), R.round_to(1 + 0.1 * rng.standard_normal(N), dtype)
+    wt = ops.tile_weights(dev(w, dtype))
+    part = ops.linear_tiled(dev(x, dtype), wt, N, k_groups=G, epilogue=ops.EPI_PARTIAL, tiles_per_wg=104)
+    rd = dev(res, dtype)
+    out = torch.empty(M, N, dtype=DT[dtype], device="cuda")
+    ops.fused_add_rms_norm_partial(part, G, rd, dev(nw, dtype), 1e-5, out)
+    y_ref, z_ref = R.fused_add_rms_norm(R.linear(x, w, None, dtype), res, nw, 1e-5, dtype)
+    assert (host(rd) != z_ref).mean() <= 0.02                  # different summation order: rare 1-ulp flips
+    assert_ulp_close(host(rd), z_ref, dtype, 0.02)
+    d = np.abs(host(out) - y_ref)
+    assert (d <= 4 * ULP[dtype] * np.abs(y_ref) + 1e-3).all()

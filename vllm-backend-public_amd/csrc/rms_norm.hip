@@ -6,6 +6,11 @@
 // with wave64 shuffles + one LDS exchange, and writes the result with 16-byte
 // stores.  HBM-bound: 2 bytes in + 2 bytes out per element (plus the residual
 // read/write in the fused form).
+//
+// The PART form takes its x from the fp32 partial-sum slabs a K-split GEMM left
+// behind ([slab][token][hidden]): x = round(slab_0 + slab_1 + ... + bias), summed
+// in slab order, so the GEMM's reduction, the residual add and the norm are one
+// pass over the row.
 #include "common.h"
 
 namespace mi355 {
@@ -13,14 +18,16 @@ namespace mi355 {
 constexpr int kThreads = 256;
 constexpr int kMaxVec = 4;  // vectors cached per thread: 256 * 4 * 8 = 8192 elements
 
-template <typename T, bool ADD, bool CACHED>
+template <typename T, bool ADD, bool CACHED, bool PART>
 __global__ __launch_bounds__(kThreads) void rms_norm_kernel(
     uint16_t* out, const uint16_t* x, uint16_t* residual,  // out may alias x
     const uint16_t* __restrict__ weight, int hidden, int64_t x_stride, int64_t out_stride,
-    int64_t res_stride, float eps) {
+    int64_t res_stride, float eps, const float* __restrict__ partial, int num_slabs, int64_t slab_stride,
+    const uint16_t* __restrict__ bias) {
   const int64_t row = blockIdx.x;
   const int nvec = hidden >> 3;
-  const uint4* xr = reinterpret_cast<const uint4*>(x + row * x_stride);
+  const uint4* xr = PART ? nullptr : reinterpret_cast<const uint4*>(x + row * x_stride);
+  const float* pr = PART ? partial + row * hidden : nullptr;
   uint4* rr = ADD ? reinterpret_cast<uint4*>(residual + row * res_stride) : nullptr;
   uint4* orow = reinterpret_cast<uint4*>(out + row * out_stride);
   const uint4* wv = reinterpret_cast<const uint4*>(weight);
@@ -29,7 +36,26 @@ __global__ __launch_bounds__(kThreads) void rms_norm_kernel(
   float ss = 0.f;
 
   auto load_row_vec = [&](int v, float (&f)[8]) {
-    unpack8<T>(xr[v], f);
+    if (PART) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = 0.f;
+      for (int s = 0; s < num_slabs; ++s) {
+        const float4* p = reinterpret_cast<const float4*>(pr + s * slab_stride + 8 * v);
+        const float4 a = p[0], b = p[1];
+        f[0] += a.x; f[1] += a.y; f[2] += a.z; f[3] += a.w;
+        f[4] += b.x; f[5] += b.y; f[6] += b.z; f[7] += b.w;
+      }
+      if (bias != nullptr) {
+        float bb[8];
+        unpack8<T>(reinterpret_cast<const uint4*>(bias)[v], bb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += bb[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = round_f<T>(f[j]);
+    } else {
+      unpack8<T>(xr[v], f);
+    }
     if (ADD) {
       float r[8];
       unpack8<T>(rr[v], r);
@@ -92,12 +118,22 @@ __global__ __launch_bounds__(kThreads) void rms_norm_kernel(
   }
 }
 
-template <bool ADD>
+template <bool ADD, bool PART = false>
 static int32_t launch(void* out, const void* x, void* residual, const void* weight,
                       int64_t num_tokens, int32_t hidden, int64_t x_stride, int64_t out_stride,
-                      int64_t res_stride, float eps, int32_t dtype, void* stream) {
-  const char* name = ADD ? "mi355_fused_add_rms_norm" : "mi355_rms_norm";
+                      int64_t res_stride, float eps, int32_t dtype, void* stream,
+                      const float* partial = nullptr, int num_slabs = 0, int64_t slab_stride = 0,
+                      const void* bias = nullptr) {
+  const char* name = PART ? "mi355_fused_add_rms_norm_partial" : ADD ? "mi355_fused_add_rms_norm" : "mi355_rms_norm";
   MI355_REQUIRE(out && x && weight && (!ADD || residual), MI355_ERR_INVALID, "%s: null pointer", name);
+  if (PART) {
+    MI355_REQUIRE(num_slabs >= 1 && num_slabs <= 64, MI355_ERR_INVALID, "%s: num_slabs %d outside [1, 64]", name,
+                  num_slabs);
+    MI355_REQUIRE(slab_stride >= num_tokens * hidden && slab_stride % 4 == 0, MI355_ERR_INVALID,
+                  "%s: slab_stride %lld must be >= num_tokens * hidden and a multiple of 4", name,
+                  (long long)slab_stride);
+    MI355_REQUIRE(bias == nullptr || aligned16(bias), MI355_ERR_INVALID, "%s: bias must be 16-byte aligned", name);
+  }
   MI355_REQUIRE(num_tokens >= 0 && num_tokens <= 0x7FFFFFFF, MI355_ERR_INVALID,
                 "%s: num_tokens %lld out of range", name, (long long)num_tokens);
   MI355_REQUIRE(hidden > 0 && hidden % 8 == 0, MI355_ERR_UNSUPPORTED,
@@ -118,9 +154,10 @@ static int32_t launch(void* out, const void* x, void* residual, const void* weig
   auto* xi = static_cast<const uint16_t*>(x);
   auto* r = static_cast<uint16_t*>(residual);
   auto* w = static_cast<const uint16_t*>(weight);
-#define MI355_RMS_LAUNCH(TT, CC)                                                                   \
-  hipLaunchKernelGGL((rms_norm_kernel<TT, ADD, CC>), grid, block, 0, s, o, xi, r, w, hidden, x_stride, \
-                     out_stride, res_stride, eps)
+  auto* bp = static_cast<const uint16_t*>(bias);
+#define MI355_RMS_LAUNCH(TT, CC)                                                                         \
+  hipLaunchKernelGGL((rms_norm_kernel<TT, ADD, CC, PART>), grid, block, 0, s, o, xi, r, w, hidden, x_stride, \
+                     out_stride, res_stride, eps, partial, num_slabs, slab_stride, bp)
   if (dtype == MI355_BF16) {
     if (cached) MI355_RMS_LAUNCH(BF16, true); else MI355_RMS_LAUNCH(BF16, false);
   } else {
@@ -145,4 +182,14 @@ extern "C" int32_t mi355_fused_add_rms_norm(void* out, const void* x, void* resi
                                             int32_t dtype, void* stream) {
   return mi355::launch<true>(out, x, residual, weight, num_tokens, hidden, x_stride, out_stride,
                              residual_stride, eps, dtype, stream);
+}
+
+extern "C" int32_t mi355_fused_add_rms_norm_partial(void* out, const float* partial, int32_t num_slabs,
+                                                    int64_t slab_stride, const void* bias, void* residual,
+                                                    const void* weight, int64_t num_tokens, int32_t hidden,
+                                                    int64_t out_stride, int64_t residual_stride, float eps,
+                                                    int32_t dtype, void* stream) {
+  // `partial` stands in for x in the shared argument checks (16-byte alignment, non-null)
+  return mi355::launch<true, true>(out, partial, residual, weight, num_tokens, hidden, hidden, out_stride,
+                                   residual_stride, eps, dtype, stream, partial, num_slabs, slab_stride, bias);
 }

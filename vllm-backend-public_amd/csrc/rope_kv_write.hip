@@ -10,16 +10,22 @@
 // paged_attn_decode.hip).  All loads are 16-byte vectors; cos/sin come from a
 // precomputed table in the model dtype.  HBM-bound and small: 2 bytes in, 2 out
 // per q element, 2 in / 4 out per k element, 2 in / 2 out per v element.
+//
+// The PART form reads the projection from the fp32 partial-sum slabs of a
+// K-split GEMM ([slab][token][width]) instead: qkv = round(slab_0 + slab_1 + ...
+// + bias) is formed on the fly, and q, k (rotated) and v are all written to the
+// packed 16-bit rows, which then hold what the plain form leaves there.
 #include "common.h"
 
 namespace mi355 {
 
-template <typename T>
+template <typename T, bool PART>
 __global__ __launch_bounds__(256) void rope_kv_write_kernel(
     uint16_t* __restrict__ qkv, int64_t qkv_stride, const int64_t* __restrict__ positions,
     const uint16_t* __restrict__ cos_sin, int max_position, const int64_t* __restrict__ slot_mapping,
     uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache, int num_blocks, int64_t num_tokens,
-    int num_heads, int num_kv_heads, int head_dim) {
+    int num_heads, int num_kv_heads, int head_dim, const float* __restrict__ partial, int num_slabs,
+    int64_t slab_stride, const uint16_t* __restrict__ bias) {
   const int half = head_dim >> 1;
   const int chunks = half >> 3;  // 8 pairs per chunk
   const int heads_total = num_heads + 2 * num_kv_heads;
@@ -35,7 +41,38 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(
     uint16_t* base = qkv + tok * qkv_stride + static_cast<int64_t>(head) * head_dim;
     uint4* p1 = reinterpret_cast<uint4*>(base + 8 * c);
     uint4* p2 = reinterpret_cast<uint4*>(base + half + 8 * c);
-    uint4 r1 = *p1, r2 = *p2;
+    uint4 r1, r2;
+    if (PART) {
+      const int col = head * head_dim + 8 * c;
+      const float* pr = partial + tok * (static_cast<int64_t>(heads_total) * head_dim) + col;
+      float f1[8], f2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f1[j] = f2[j] = 0.f;
+      for (int s = 0; s < num_slabs; ++s) {
+        const float4* a = reinterpret_cast<const float4*>(pr + s * slab_stride);
+        const float4* b = reinterpret_cast<const float4*>(pr + s * slab_stride + half);
+        const float4 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+        f1[0] += a0.x; f1[1] += a0.y; f1[2] += a0.z; f1[3] += a0.w;
+        f1[4] += a1.x; f1[5] += a1.y; f1[6] += a1.z; f1[7] += a1.w;
+        f2[0] += b0.x; f2[1] += b0.y; f2[2] += b0.z; f2[3] += b0.w;
+        f2[4] += b1.x; f2[5] += b1.y; f2[6] += b1.z; f2[7] += b1.w;
+      }
+      if (bias != nullptr) {
+        float b1[8], b2[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(bias + col), b1);
+        unpack8<T>(*reinterpret_cast<const uint4*>(bias + col + half), b2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          f1[j] += b1[j];
+          f2[j] += b2[j];
+        }
+      }
+      r1 = pack8<T>(f1);
+      r2 = pack8<T>(f2);
+    } else {
+      r1 = *p1;
+      r2 = *p2;
+    }
 
     const bool is_v = head >= num_heads + num_kv_heads;
     if (!is_v) {
@@ -59,6 +96,9 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(
       }
       r1 = pack8<T>(o1);
       r2 = pack8<T>(o2);
+      *p1 = r1;
+      *p2 = r2;
+    } else if (PART) {
       *p1 = r1;
       *p2 = r2;
     }
@@ -89,16 +129,12 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(
   }
 }
 
-}  // namespace mi355
-
-extern "C" int32_t mi355_rope_kv_write(void* qkv, int64_t qkv_stride, const int64_t* positions,
-                                       const void* cos_sin, int32_t max_position,
-                                       const int64_t* slot_mapping, void* k_cache, void* v_cache,
-                                       int32_t num_blocks, int64_t num_tokens, int32_t num_heads,
-                                       int32_t num_kv_heads, int32_t head_dim, int32_t dtype,
-                                       void* stream) {
-  using namespace mi355;
-  const char* name = "mi355_rope_kv_write";
+template <bool PART>
+static int32_t launch_rope(const char* name, void* qkv, int64_t qkv_stride, const int64_t* positions,
+                           const void* cos_sin, int32_t max_position, const int64_t* slot_mapping, void* k_cache,
+                           void* v_cache, int32_t num_blocks, int64_t num_tokens, int32_t num_heads,
+                           int32_t num_kv_heads, int32_t head_dim, int32_t dtype, void* stream,
+                           const float* partial, int32_t num_slabs, int64_t slab_stride, const void* bias) {
   MI355_REQUIRE(qkv && positions && cos_sin && slot_mapping && k_cache && v_cache, MI355_ERR_INVALID,
                 "%s: null pointer", name);
   MI355_REQUIRE(num_tokens >= 0 && num_tokens <= 0x7FFFFFFF, MI355_ERR_INVALID,
@@ -115,6 +151,15 @@ extern "C" int32_t mi355_rope_kv_write(void* qkv, int64_t qkv_stride, const int6
                 MI355_ERR_INVALID, "%s: pointers must be 16-byte aligned", name);
   MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED,
                 "%s: dtype %d not supported (bf16/fp16 only)", name, dtype);
+  if (PART) {
+    MI355_REQUIRE(partial && aligned16(partial) && (bias == nullptr || aligned16(bias)), MI355_ERR_INVALID,
+                  "%s: partial/bias must be non-null (partial) and 16-byte aligned", name);
+    MI355_REQUIRE(num_slabs >= 1 && num_slabs <= 64, MI355_ERR_INVALID, "%s: num_slabs %d outside [1, 64]", name,
+                  num_slabs);
+    MI355_REQUIRE(slab_stride >= num_tokens * width && slab_stride % 4 == 0, MI355_ERR_INVALID,
+                  "%s: slab_stride %lld must be >= num_tokens * width and a multiple of 4", name,
+                  (long long)slab_stride);
+  }
   if (num_tokens == 0) return MI355_OK;
 
   const int64_t items = num_tokens * (num_heads + 2 * num_kv_heads) * (head_dim / 16);
@@ -123,14 +168,41 @@ extern "C" int32_t mi355_rope_kv_write(void* qkv, int64_t qkv_stride, const int6
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(static_cast<unsigned>(blocks)), block(256);
   if (dtype == MI355_BF16)
-    hipLaunchKernelGGL((rope_kv_write_kernel<BF16>), grid, block, 0, s, static_cast<uint16_t*>(qkv),
+    hipLaunchKernelGGL((rope_kv_write_kernel<BF16, PART>), grid, block, 0, s, static_cast<uint16_t*>(qkv),
                        qkv_stride, positions, static_cast<const uint16_t*>(cos_sin), max_position,
                        slot_mapping, static_cast<uint16_t*>(k_cache), static_cast<uint16_t*>(v_cache),
-                       num_blocks, num_tokens, num_heads, num_kv_heads, head_dim);
+                       num_blocks, num_tokens, num_heads, num_kv_heads, head_dim, partial, num_slabs,
+                       slab_stride, static_cast<const uint16_t*>(bias));
   else
-    hipLaunchKernelGGL((rope_kv_write_kernel<F16>), grid, block, 0, s, static_cast<uint16_t*>(qkv),
+    hipLaunchKernelGGL((rope_kv_write_kernel<F16, PART>), grid, block, 0, s, static_cast<uint16_t*>(qkv),
                        qkv_stride, positions, static_cast<const uint16_t*>(cos_sin), max_position,
                        slot_mapping, static_cast<uint16_t*>(k_cache), static_cast<uint16_t*>(v_cache),
-                       num_blocks, num_tokens, num_heads, num_kv_heads, head_dim);
+                       num_blocks, num_tokens, num_heads, num_kv_heads, head_dim, partial, num_slabs,
+                       slab_stride, static_cast<const uint16_t*>(bias));
   return check_launch(name);
+}
+
+}  // namespace mi355
+
+extern "C" int32_t mi355_rope_kv_write(void* qkv, int64_t qkv_stride, const int64_t* positions,
+                                       const void* cos_sin, int32_t max_position,
+                                       const int64_t* slot_mapping, void* k_cache, void* v_cache,
+                                       int32_t num_blocks, int64_t num_tokens, int32_t num_heads,
+                                       int32_t num_kv_heads, int32_t head_dim, int32_t dtype,
+                                       void* stream) {
+  return mi355::launch_rope<false>("mi355_rope_kv_write", qkv, qkv_stride, positions, cos_sin, max_position,
+                                   slot_mapping, k_cache, v_cache, num_blocks, num_tokens, num_heads,
+                                   num_kv_heads, head_dim, dtype, stream, nullptr, 0, 0, nullptr);
+}
+
+extern "C" int32_t mi355_rope_kv_write_partial(void* qkv, int64_t qkv_stride, const float* partial,
+                                               int32_t num_slabs, int64_t slab_stride, const void* bias,
+                                               const int64_t* positions, const void* cos_sin,
+                                               int32_t max_position, const int64_t* slot_mapping, void* k_cache,
+                                               void* v_cache, int32_t num_blocks, int64_t num_tokens,
+                                               int32_t num_heads, int32_t num_kv_heads, int32_t head_dim,
+                                               int32_t dtype, void* stream) {
+  return mi355::launch_rope<true>("mi355_rope_kv_write_partial", qkv, qkv_stride, positions, cos_sin,
+                                  max_position, slot_mapping, k_cache, v_cache, num_blocks, num_tokens, num_heads,
+                                  num_kv_heads, head_dim, dtype, stream, partial, num_slabs, slab_stride, bias);
 }

@@ -41,7 +41,7 @@ def init_distributed(tp_size: int):
 
 
 def plan_num_blocks(args: EngineArgs, cfg: ModelConfig, tp_size: int, num_layers: int, max_model_len: int,
-                    elem_size: int, device) -> int:
+                    elem_size: int, device, extra_reserve: int = 0) -> int:
     """KV pages to allocate: what max_num_seqs sequences of max_model_len tokens
     can ever use, capped by the memory budget (gpu_memory_utilization of the card
     minus what is already resident and an activation reserve).  The harness's
@@ -51,7 +51,7 @@ def plan_num_blocks(args: EngineArgs, cfg: ModelConfig, tp_size: int, num_layers
     blocks_per_seq = (max_model_len + BLOCK_SIZE - 1) // BLOCK_SIZE
     want = args.max_num_seqs * blocks_per_seq + 1
     free, total = torch.cuda.mem_get_info(device)
-    reserve = 6 << 30
+    reserve = (6 << 30) + int(extra_reserve)
     util = args.gpu_memory_utilization if args.gpu_memory_utilization and args.gpu_memory_utilization > 0 else 0.9
     budget = min(free - reserve, int(total * util) - (total - free) - reserve)
     fit = max(int(budget // per_block), 0)
@@ -86,8 +86,13 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
                         args.model)
         weights = W.synthetic(cfg, dtype, device, seed=args.seed, **kw)
     tp = kw["tp_size"]
+    # the runner keeps a second, fragment-tiled copy of the per-layer matrices (TP=1 only)
+    tiled_bytes = 0
+    if tp == 1:
+        tiled_bytes = sum(t.numel() * t.element_size() for lw in weights.layers
+                          for t in (lw.qkv_w, lw.o_w, lw.gate_up_w, lw.down_w))
     num_blocks = plan_num_blocks(args, cfg, tp, len(weights.layers), max_model_len,
-                                 torch.empty(0, dtype=dtype).element_size(), device)
+                                 torch.empty(0, dtype=dtype).element_size(), device, extra_reserve=tiled_bytes)
     runner = ModelRunner(cfg, weights, dtype, device, num_blocks, args.max_num_seqs, max_model_len,
                          tp_rank=rank, tp_size=tp, tp_group=group, use_graphs=not args.enforce_eager,
                          decode_splits=decode_splits)

@@ -2,9 +2,12 @@
 attention, o-proj (+all-reduce under TP), norm, gate_up, SwiGLU, down] -> norm ->
 lm_head -> greedy token.
 
-The hot operators go through the C ABI (mi355_decode.ops -> libmi355_decode.so);
-the linear layers are plain GEMMs on the same stream.  PyTorch only owns memory,
-streams and the process group.  The decode step works on statically allocated
+The hot operators go through the C ABI (mi355_decode.ops -> libmi355_decode.so).
+Decode steps of up to 32 sequences on one GPU run their per-layer linear layers
+through the weight-streaming GEMM on fragment-tiled weight copies (K-split layers
+hand fp32 partial sums to the norm / rotary kernels, the SwiGLU gate is applied in
+the gate_up epilogue); larger batches, prefill and the lm_head use library GEMMs on
+the row-major weights.  PyTorch only owns memory, streams and the process group.  The decode step works on statically allocated
 buffers and is captured once per batch-size bucket into a HIP graph (a decode
 step is ~300 short kernels; replay removes the per-launch host cost); prefill
 runs eagerly.
@@ -53,7 +56,7 @@ class ModelRunner:
     def __init__(self, cfg: ModelConfig, weights: ModelWeights, dtype: torch.dtype, device,
                  num_blocks: int, max_num_seqs: int, max_model_len: int, tp_rank: int = 0,
                  tp_size: int = 1, tp_group=None, use_graphs: bool = True,
-                 decode_splits: Optional[int] = None):
+                 decode_splits: Optional[int] = None, tiled_linears: Optional[bool] = None):
         self.cfg, self.w, self.dtype, self.device = cfg, weights, dtype, torch.device(device)
         self.tp_rank, self.tp_size, self.tp_group = tp_rank, tp_size, tp_group
         self.nh = cfg.num_attention_heads // tp_size
@@ -109,12 +112,65 @@ class ModelRunner:
                                    dtype=torch.uint8, device=dev)
         self.graphs = {}
         self.buckets = batch_buckets(B)
+        self._init_tiled(tiled_linears)
         # pinned host staging for the packed inputs and the sampled tokens
         self.h64 = torch.zeros(3 * B, dtype=torch.int64).pin_memory()
         self.h32 = torch.zeros(B + B * self.max_blocks, dtype=torch.int32).pin_memory()
         self.h_next = torch.zeros(B, dtype=torch.int64).pin_memory()
 
     # ------------------------------------------------------------------ #
+    def _init_tiled(self, want: Optional[bool]) -> None:
+        """Fragment-tiled copies of the per-layer weights for decode batches <= 32.
+        Only without tensor parallelism: the K-split o/down projections leave fp32
+        partial sums that the next norm kernel consumes, which has no place for the
+        all-reduce a sharded o/down projection needs."""
+        import os
+        if want is None:
+            want = os.environ.get("MI355_TILED_LINEARS", "1") != "0"
+        self.tiled = None
+        if not want or self.tp_size != 1 or self.dtype not in (torch.bfloat16, torch.float16):
+            return
+        shapes = {"qkv": (self.qw, self.H, True), "o": (self.H, self.nh * self.d, True),
+                  "gu": (2 * self.F, self.H, False), "down": (self.H, self.F, True)}
+        plans = {k: ops.plan_linear_tiled(n, kk, split) for k, (n, kk, split) in shapes.items()}
+        if any(p is None for p in plans.values()) or (2 * self.F) % 32:
+            return
+        self.tiled_plans = plans
+        self.tiled_max_m = min(ops.LINEAR_TILED_MAX_M, self.max_num_seqs)
+        self.tiled = []
+        for lw in self.w.layers:
+            self.tiled.append({"qkv": ops.tile_weights(lw.qkv_w), "o": ops.tile_weights(lw.o_w),
+                               "gu": ops.tile_weights(lw.gate_up_w, interleave_halves=True),
+                               "down": ops.tile_weights(lw.down_w)})
+        m = self.tiled_max_m
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.part_qkv = torch.empty(plans["qkv"][1] * m * self.qw, **f32)
+        self.part_o = torch.empty(plans["o"][1] * m * self.H, **f32)
+        self.part_dn = torch.empty(plans["down"][1] * m * self.H, **f32)
+
+    def _decode_layers_tiled(self, b: int, pos, slots, bt, ctx, splits) -> None:
+        """All decoder layers + the final norm for b <= 32 decode tokens; leaves the
+        normed hidden state in self.x[:b]."""
+        resid, x, qkv, attn, act = self.resid[:b], self.x[:b], self.qkv[:b], self.attn[:b], self.act[:b]
+        P = ops.EPI_PARTIAL
+        (tq, gq), (to, go), (tg, _), (td, gd) = (self.tiled_plans[k] for k in ("qkv", "o", "gu", "down"))
+        for i, (lw, tw) in enumerate(zip(self.w.layers, self.tiled)):
+            if i == 0:
+                ops.rms_norm(resid, lw.input_norm, self.eps, out=x)
+            else:
+                ops.fused_add_rms_norm_partial(self.part_dn, gd, resid, lw.input_norm, self.eps, x)
+            ops.linear_tiled(x, tw["qkv"], self.qw, partial=self.part_qkv, tiles_per_wg=tq, k_groups=gq, epilogue=P)
+            ops.rope_kv_write(qkv, pos, self.cos_sin, slots, self.k_cache[i], self.v_cache[i], self.nh, self.nkv,
+                              self.d, partial=self.part_qkv, num_slabs=gq, bias=lw.qkv_b)
+            ops.paged_attn_decode(qkv[:, : self.nh * self.d], self.k_cache[i], self.v_cache[i], bt, ctx,
+                                  self.nh, self.nkv, self.d, self.scale, num_splits=splits,
+                                  workspace=self.attn_ws, out=attn)
+            ops.linear_tiled(attn, tw["o"], self.H, partial=self.part_o, tiles_per_wg=to, k_groups=go, epilogue=P)
+            ops.fused_add_rms_norm_partial(self.part_o, go, resid, lw.post_norm, self.eps, x)
+            ops.linear_tiled(x, tw["gu"], 2 * self.F, out=act, tiles_per_wg=tg, epilogue=ops.EPI_SILU_MUL)
+            ops.linear_tiled(act, tw["down"], self.H, partial=self.part_dn, tiles_per_wg=td, k_groups=gd, epilogue=P)
+        ops.fused_add_rms_norm_partial(self.part_dn, gd, resid, self.w.final_norm, self.eps, x)
+
     def kv_cache_bytes_per_block(self) -> int:
         return 2 * self.L * self.nkv * BLOCK_SIZE * self.d * self.k_cache[0].element_size()
 
@@ -161,6 +217,11 @@ class ModelRunner:
         o, gu, act, dn = self.o[:b], self.gu[:b], self.act[:b], self.dn[:b]
         splits = self._splits_for(b)
         torch.index_select(self.w.embed, 0, ids, out=resid)
+        if self.tiled is not None and b <= self.tiled_max_m:
+            self._decode_layers_tiled(b, pos, slots, bt, ctx, splits)
+            torch.mm(x, self.w.lm_head.t(), out=self.logits[:b])
+            ops.argmax(self.logits[:b], out=self.next_ids[:b])
+            return
 
         def attend(i, qkv_, attn_):
             ops.rope_kv_write(qkv_, pos, self.cos_sin, slots, self.k_cache[i], self.v_cache[i],

@@ -69,11 +69,44 @@ def fused_add_rms_norm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Te
     return out
 
 
+def _check_partial(partial: torch.Tensor, num_slabs: int, rows: int, width: int) -> None:
+    _dev(partial, "partial")
+    if (partial.dtype != torch.float32 or not partial.is_contiguous() or num_slabs < 1
+            or partial.numel() < num_slabs * rows * width):
+        raise ValueError("partial must be contiguous float32 holding [num_slabs, rows, width]")
+
+
+def fused_add_rms_norm_partial(partial: torch.Tensor, num_slabs: int, residual: torch.Tensor,
+                               weight: torch.Tensor, eps: float, out: torch.Tensor,
+                               bias: torch.Tensor | None = None):
+    """fused_add_rms_norm whose x is round(sum of the fp32 slabs partial[:num_slabs] (+ bias)):
+    the partial-sum output of linear_tiled(..., epilogue=EPI_PARTIAL) over the same rows."""
+    dt = _dt16(residual, "residual")
+    _dev(weight, "weight"), _dev(out, "out")
+    T, H = residual.shape
+    _check_partial(partial, num_slabs, T, H)
+    if weight.dtype != residual.dtype or weight.numel() != H or not weight.is_contiguous():
+        raise ValueError("weight must be contiguous [hidden] in the dtype of residual")
+    if out.dtype != residual.dtype or tuple(out.shape) != (T, H):
+        raise ValueError("out must match residual")
+    if bias is not None and (bias.dtype != residual.dtype or bias.numel() != H or not bias.is_contiguous()):
+        raise ValueError("bias must be contiguous [hidden] in the dtype of residual")
+    check(lib.mi355_fused_add_rms_norm_partial(out.data_ptr(), partial.data_ptr(), num_slabs, T * H,
+                                               bias.data_ptr() if bias is not None else 0, residual.data_ptr(),
+                                               weight.data_ptr(), T, H, _rows(out, "out"),
+                                               _rows(residual, "residual"), float(eps), dt, _stream()))
+    return out
+
+
 def rope_kv_write(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: torch.Tensor,
                   slot_mapping: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
-                  num_heads: int, num_kv_heads: int, head_dim: int) -> None:
+                  num_heads: int, num_kv_heads: int, head_dim: int, partial: torch.Tensor | None = None,
+                  num_slabs: int = 0, bias: torch.Tensor | None = None) -> None:
     """In-place rotary embedding on the q|k parts of ``qkv`` + paged store of k, v.
-    k_cache [blocks, kv_heads, 16, head_dim]; v_cache [blocks, kv_heads, head_dim, 16]."""
+    k_cache [blocks, kv_heads, 16, head_dim]; v_cache [blocks, kv_heads, head_dim, 16].
+    With ``partial`` (fp32 [num_slabs, tokens, width], the partial-sum output of
+    linear_tiled) the rows are first formed as round(sum of slabs (+ bias)) and
+    written to ``qkv`` in full."""
     dt = _dt16(qkv, "qkv")
     T = qkv.shape[0]
     for t, n in ((positions, "positions"), (slot_mapping, "slot_mapping")):
@@ -90,6 +123,16 @@ def rope_kv_write(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: torch.Ten
         raise ValueError("cos_sin must be contiguous [max_position, head_dim] in the dtype of qkv")
     if qkv.shape[1] != (num_heads + 2 * num_kv_heads) * head_dim:
         raise ValueError("qkv width must be (num_heads + 2*num_kv_heads) * head_dim")
+    if partial is not None:
+        _check_partial(partial, num_slabs, T, qkv.shape[1])
+        if bias is not None and (bias.dtype != qkv.dtype or bias.numel() != qkv.shape[1] or not bias.is_contiguous()):
+            raise ValueError("bias must be contiguous [width] in the dtype of qkv")
+        check(lib.mi355_rope_kv_write_partial(
+            qkv.data_ptr(), _rows(qkv, "qkv"), partial.data_ptr(), num_slabs, T * qkv.shape[1],
+            bias.data_ptr() if bias is not None else 0, positions.data_ptr(), cos_sin.data_ptr(), cos_sin.shape[0],
+            slot_mapping.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), nb, T, num_heads, num_kv_heads,
+            head_dim, dt, _stream()))
+        return
     check(lib.mi355_rope_kv_write(qkv.data_ptr(), _rows(qkv, "qkv"), positions.data_ptr(), cos_sin.data_ptr(),
                                   cos_sin.shape[0], slot_mapping.data_ptr(), k_cache.data_ptr(),
                                   v_cache.data_ptr(), nb, T, num_heads, num_kv_heads, head_dim, dt, _stream()))
@@ -232,3 +275,83 @@ def sample(logits: torch.Tensor, temperature: torch.Tensor, top_k: torch.Tensor,
                                      _DT[logits.dtype], temperature.data_ptr(), top_k.data_ptr(), top_p.data_ptr(),
                                      seeds.data_ptr(), steps.data_ptr(), _stream()))
     return out
+
+
+EPI_STORE, EPI_SILU_MUL, EPI_PARTIAL = 0, 1, 2
+LINEAR_TILED_MAX_M = 32
+LINEAR_TILED_K_MULTIPLE = 1024       # (512 with the 104/108 geometries)
+
+
+def plan_linear_tiled(N: int, K: int, split_k: bool):
+    """(tiles_per_wg, k_groups) for linear_tiled on an [N, K] weight, or None when the
+    kernel does not cover the shape.  One workgroup per CU (>= ~192 workgroups) is what
+    saturates the weight stream: wide layers take 8 tiles per workgroup unsplit; narrow
+    ones (N/16/4 < 192 workgroups) split K over workgroups when the caller can consume
+    fp32 partial sums, using 512-wide x slices so two workgroups share a CU."""
+    if K % 512:
+        return None
+    tiles_total = (N + 15) // 16
+    if not split_k or tiles_total >= 8 * 160:
+        if K % 1024:
+            return (104 if tiles_total < 8 * 160 else 108), 1
+        return (8 if tiles_total >= 8 * 160 else 4), 1
+    wgs = -(-tiles_total // 4)
+    phases = K // 512
+    groups = 1
+    for g in (1, 2, 4, 7, 8):
+        if phases % g == 0:
+            groups = g
+            if wgs * g >= 192:
+                break
+    return 104, groups
+
+
+def tile_weights(weight: torch.Tensor, interleave_halves: bool = False) -> torch.Tensor:
+    """Row-major [N, K] -> fragment-tiled flat tensor for linear_tiled (done once at load)."""
+    _dt16(weight, "weight")
+    if weight.dim() != 2 or not weight.is_contiguous():
+        raise ValueError("weight must be contiguous [N, K]")
+    N, K = weight.shape
+    n = int(lib.mi355_tiled_weight_elems(N, K))
+    if n == 0:
+        raise ValueError(f"K {K} must be a multiple of 32")
+    out = torch.empty(n, dtype=weight.dtype, device=weight.device)
+    check(lib.mi355_tile_weights(out.data_ptr(), weight.data_ptr(), N, K, int(bool(interleave_halves)), _stream()))
+    return out
+
+
+def linear_tiled(x: torch.Tensor, w_tiled: torch.Tensor, N: int, bias: torch.Tensor | None = None,
+                 out: torch.Tensor | None = None, partial: torch.Tensor | None = None, tiles_per_wg: int = 0,
+                 k_groups: int = 1, epilogue: int = EPI_STORE):
+    """y = x @ W.T on fragment-tiled weights (M <= 32, K % 1024 == 0).  Returns `out`
+    ([M, N], or [M, N/2] with the SwiGLU epilogue) or `partial` ([k_groups, M, N] fp32)."""
+    dt = _dt16(x, "x")
+    _dev(w_tiled, "w_tiled")
+    M, K = x.shape
+    if w_tiled.dtype != x.dtype or w_tiled.numel() != int(lib.mi355_tiled_weight_elems(N, K)):
+        raise ValueError("w_tiled does not match (N, K) / dtype")
+    tiles_total = (N + 15) // 16
+    if tiles_per_wg == 0:                         # 8 tiles (waves) per workgroup once that still fills the chip
+        tiles_per_wg = 8 if -(-tiles_total // 8) * k_groups >= 160 else 4
+    y_ptr = p_ptr = 0
+    y_stride = 0
+    if epilogue == EPI_PARTIAL:
+        if partial is None:
+            partial = torch.empty((k_groups, M, N), dtype=torch.float32, device=x.device)
+        elif partial.dtype != torch.float32 or partial.numel() < k_groups * M * N or not partial.is_contiguous():
+            raise ValueError("partial must be contiguous float32 [k_groups, M, N]")
+        p_ptr = partial.data_ptr()
+        ret = partial
+    else:
+        width = N // 2 if epilogue == EPI_SILU_MUL else N
+        if out is None:
+            out = torch.empty((M, width), dtype=x.dtype, device=x.device)
+        elif out.dtype != x.dtype or tuple(out.shape) != (M, width):
+            raise ValueError(f"out must be [M, {width}] in the dtype of x")
+        y_ptr, y_stride, ret = out.data_ptr(), _rows(out, "out"), out
+    if bias is not None and (bias.dtype != x.dtype or bias.numel() != N or not bias.is_contiguous()):
+        raise ValueError("bias must be contiguous [N] in the dtype of x")
+    check(lib.mi355_linear_tiled(y_ptr, y_stride, p_ptr, x.data_ptr(), _rows(x, "x"), w_tiled.data_ptr(),
+                                 bias.data_ptr() if bias is not None else 0, M, N, K, tiles_per_wg, k_groups,
+                                 epilogue, dt, _stream()))
+    return ret
