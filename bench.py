@@ -81,10 +81,12 @@ def make_prompts(vocab, batch, plen, seed):
 
 
 def time_kernels(engine, batch, ctx_len):
-    """Average launch time of each kernel of the decode step, with HIP events on
-    the launch stream.  Launches walk over the layers so that consecutive launches
-    touch different weights / KV pages (nothing is served from the Infinity Cache
-    that a real step would have to fetch from HBM)."""
+    """Average launch time of each kernel of the decode step.  Each kernel is
+    captured into a HIP graph that walks over the layers (consecutive launches
+    touch different weights / KV pages, so nothing is served from the Infinity
+    Cache that a real step would fetch from HBM) and the replay is timed with HIP
+    events on the stream it is launched on: the same back-to-back launch
+    conditions as inside the decode-step graph, without host launch gaps."""
     import torch
     from mi355_decode import ops
     r = engine.runner
@@ -97,27 +99,50 @@ def time_kernels(engine, batch, ctx_len):
         for i in range(min(L, 4)):
             fn(i)
         torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                for i in range(L):
+                    fn(i)
+        g.replay()
+        torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        for _ in range(reps):
-            for i in range(L):
-                fn(i)
+        for _ in range(3):
+            g.replay()
         e.record()
         e.synchronize()
-        us = s.elapsed_time(e) * 1000.0 / (reps * L)
+        us = s.elapsed_time(e) * 1000.0 / (3 * reps * L)
         return {"us": round(us, 2), "bytes": int(bytes_per_launch),
                 "gbs": round(bytes_per_launch / us / 1e3, 1), "frac": round(bytes_per_launch / us / 1e3 / HBM_PEAK_GBS, 4)}
 
     es = 2
     x, qkv, attn, o, gu, act, dn, resid = r.x[:b], r.qkv[:b], r.attn[:b], r.o[:b], r.gu[:b], r.act[:b], r.dn[:b], r.resid[:b]
     W = r.w.layers
-    gemm = lambda m, n, k: (n * k + m * k + m * n) * es   # noqa: E731
-    out["gemm_gate_up"] = timed(lambda i: torch.mm(x, W[i].gate_up_w.t(), out=gu), gemm(b, 2 * r.F, r.H))
-    out["gemm_down"] = timed(lambda i: torch.mm(act, W[i].down_w.t(), out=dn), gemm(b, r.H, r.F))
-    out["gemm_qkv"] = timed(lambda i: torch.mm(x, W[i].qkv_w.t(), out=qkv), gemm(b, r.qw, r.H))
-    out["gemm_o"] = timed(lambda i: torch.mm(attn, W[i].o_w.t(), out=o), gemm(b, r.H, r.nh * r.d))
+    gemm = lambda m, n, k, out_es=es: n * k * es + m * k * es + m * n * out_es   # noqa: E731
+    tiled = r.tiled is not None and b <= r.tiled_max_m
+    if tiled:
+        T, P = r.tiled, ops.EPI_PARTIAL
+        (tq, gq), (to, go), (tg, _), (td, gd) = (r.tiled_plans[k] for k in ("qkv", "o", "gu", "down"))
+        out["impl"] = ("hand-written weight-streaming GEMMs on fragment-tiled weights (linear_tiled_kernel); "
+                       f"geometry qkv {tq}/{gq}, o {to}/{go}, gate_up {tg}/1 + SwiGLU epilogue, down {td}/{gd}")
+        out["gemm_gate_up"] = timed(lambda i: ops.linear_tiled(x, T[i]["gu"], 2 * r.F, out=act, tiles_per_wg=tg,
+                                                               epilogue=ops.EPI_SILU_MUL),
+                                    2 * r.F * r.H * es + b * r.H * es + b * r.F * es)
+        out["gemm_down"] = timed(lambda i: ops.linear_tiled(act, T[i]["down"], r.H, partial=r.part_dn, tiles_per_wg=td,
+                                                            k_groups=gd, epilogue=P), gemm(b, r.H, r.F, 4 * gd))
+        out["gemm_qkv"] = timed(lambda i: ops.linear_tiled(x, T[i]["qkv"], r.qw, partial=r.part_qkv, tiles_per_wg=tq,
+                                                           k_groups=gq, epilogue=P), gemm(b, r.qw, r.H, 4 * gq))
+        out["gemm_o"] = timed(lambda i: ops.linear_tiled(attn, T[i]["o"], r.H, partial=r.part_o, tiles_per_wg=to,
+                                                         k_groups=go, epilogue=P), gemm(b, r.H, r.nh * r.d, 4 * go))
+    else:
+        out["impl"] = "library GEMMs (hipBLASLt through torch.mm) on row-major weights"
+        out["gemm_gate_up"] = timed(lambda i: torch.mm(x, W[i].gate_up_w.t(), out=gu), gemm(b, 2 * r.F, r.H))
+        out["gemm_down"] = timed(lambda i: torch.mm(act, W[i].down_w.t(), out=dn), gemm(b, r.H, r.F))
+        out["gemm_qkv"] = timed(lambda i: torch.mm(x, W[i].qkv_w.t(), out=qkv), gemm(b, r.qw, r.H))
+        out["gemm_o"] = timed(lambda i: torch.mm(attn, W[i].o_w.t(), out=o), gemm(b, r.H, r.nh * r.d))
     lm = r.w.lm_head
-    out["gemm_lm_head"] = timed(lambda i: torch.mm(x, lm.t(), out=r.logits[:b]), gemm(b, r.V, r.H))
+    out["gemm_lm_head"] = timed(lambda i: r.lm_head_logits(x, r.logits[:b]), gemm(b, r.V, r.H))
 
     # attention over the live cache, at the context lengths of the last timed step
     n64, n32 = r.host_inputs()
@@ -131,11 +156,22 @@ def time_kernels(engine, batch, ctx_len):
                                         r.nh, r.nkv, r.d, r.scale, num_splits=splits, workspace=r.attn_ws, out=attn),
         kv_bytes)
     out["paged_attn_decode"]["splits"] = splits
-    out["rope_kv_write"] = timed(
-        lambda i: ops.rope_kv_write(qkv, r.positions[:b], r.cos_sin, r.slots[:b], r.k_cache[i], r.v_cache[i], r.nh, r.nkv, r.d),
-        b * ((r.nh + r.nkv) * r.d * 2 + r.nkv * r.d + 2 * r.nkv * r.d) * es)
-    out["fused_add_rms_norm"] = timed(lambda i: ops.fused_add_rms_norm(o, resid, W[i].post_norm, r.eps, out=x), 5 * b * r.H * es)
-    out["silu_and_mul"] = timed(lambda i: ops.silu_and_mul(gu, out=act), 3 * b * r.F * es)
+    rope_bytes = b * ((r.nh + r.nkv) * r.d * 2 + r.nkv * r.d + 2 * r.nkv * r.d) * es
+    if tiled:
+        out["rope_kv_write"] = timed(
+            lambda i: ops.rope_kv_write(qkv, r.positions[:b], r.cos_sin, r.slots[:b], r.k_cache[i], r.v_cache[i], r.nh,
+                                        r.nkv, r.d, partial=r.part_qkv, num_slabs=gq, bias=W[i].qkv_b),
+            b * r.qw * (4 * gq + es) + b * 2 * r.nkv * r.d * es)
+        out["fused_add_rms_norm"] = timed(
+            lambda i: ops.fused_add_rms_norm_partial(r.part_o, go, resid, W[i].post_norm, r.eps, x),
+            b * r.H * (4 * go + 3 * es))
+    else:
+        out["rope_kv_write"] = timed(
+            lambda i: ops.rope_kv_write(qkv, r.positions[:b], r.cos_sin, r.slots[:b], r.k_cache[i], r.v_cache[i], r.nh,
+                                        r.nkv, r.d), rope_bytes)
+        out["fused_add_rms_norm"] = timed(lambda i: ops.fused_add_rms_norm(o, resid, W[i].post_norm, r.eps, out=x),
+                                          5 * b * r.H * es)
+        out["silu_and_mul"] = timed(lambda i: ops.silu_and_mul(gu, out=act), 3 * b * r.F * es)
     out["argmax"] = timed(lambda i: ops.argmax(r.logits[:b], out=r.next_ids[:b]), b * r.V * es)
     return out
 
@@ -204,16 +240,20 @@ def cpu_baseline(cfg, batch, ctx_len, sample_layers=2, steps=2):
             "stock_vllm_cpu": "unavailable offline (vllm is not installed; nothing can be fetched)"}
 
 
-def pmc_traffic(prefix):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (or None)."""
+def pmc_traffic(tiled):
+    """(HBM bytes per launch of the gate/up GEMM, source) from the committed rocprofv3
+    PMC summary of this workload, or (None, None)."""
+    import re
+    name = "r01_c_pmc_traffic.json" if tiled else "r01_b_pmc_traffic.json"
+    pat = re.compile(r"linear_tiled_kernel<.*, 1> " if tiled else r"gemm_gate_up")
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")) as f:
-            for name, rec in json.load(f)["kernels"].items():
-                if name.startswith(prefix):
-                    return rec["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            for key, rec in json.load(f)["kernels"].items():
+                if pat.match(key):
+                    return rec["hbm_bytes_per_launch"], f"profiles/{name}"
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def main():
@@ -327,10 +367,15 @@ def main():
         kern = time_kernels(engine, batch, int(mean_ctx))
         result["kernels"] = kern
         dom = kern["gemm_gate_up"]
-        result["roofline"] = {"bound": "hbm", "kernel": "gate/up projection GEMM (M=%d, N=%d, K=%d)" % (batch, 2 * cfg.intermediate_size, cfg.hidden_size),
+        tiled = kern["impl"].startswith("hand-written")
+        traffic, src = pmc_traffic(tiled)
+        result["roofline"] = {"bound": "hbm",
+                              "kernel": ("gate/up projection GEMM%s (M=%d, N=%d, K=%d): %s" % (
+                                  " + SwiGLU epilogue" if tiled else "", batch, 2 * cfg.intermediate_size,
+                                  cfg.hidden_size, "linear_tiled_kernel" if tiled else "hipBLASLt")),
                               "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
-                              "traffic": pmc_traffic("gemm_gate_up"), "traffic_source": "profiles/r01_b_pmc_traffic.json "
-                              "(rocprofv3 PMC passes of this workload; not re-measured in this run)",
+                              "traffic": traffic, "traffic_source": (src or "none") +
+                              " (rocprofv3 PMC passes of this workload; not re-measured in this run)",
                               "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"]}
     if world > 1:
         dist.barrier()

@@ -576,8 +576,10 @@ def test_tiled_decode_chain_matches_plain_chain(ops):
     rd = dev(res, dtype)
     out = torch.empty(M, N, dtype=DT[dtype], device="cuda")
     ops.fused_add_rms_norm_partial(part, G, rd, dev(nw, dtype), 1e-5, out)
-    y_ref, z_ref = R.fused_add_rms_norm(R.linear(x, w, None, dtype), res, nw, 1e-5, dtype)
+    lin = R.linear(x, w, None, dtype)
+    y_ref, z_ref = R.fused_add_rms_norm(lin, res, nw, 1e-5, dtype)
     assert (host(rd) != z_ref).mean() <= 0.02                  # different summation order: rare 1-ulp flips
-    assert_ulp_close(host(rd), z_ref, dtype, 0.02)
+    # a flip is one ulp of the GEMM output, which may be larger than the sum it enters
+    assert (np.abs(host(rd) - z_ref) <= 2 * ULP[dtype] * (np.abs(lin) + np.abs(z_ref))).all()
     d = np.abs(host(out) - y_ref)
     assert (d <= 4 * ULP[dtype] * np.abs(y_ref) + 1e-3).all()

@@ -142,6 +142,8 @@ class ModelRunner:
             self.tiled.append({"qkv": ops.tile_weights(lw.qkv_w), "o": ops.tile_weights(lw.o_w),
                                "gu": ops.tile_weights(lw.gate_up_w, interleave_halves=True),
                                "down": ops.tile_weights(lw.down_w)})
+        self.lm_head_plan = ops.plan_linear_tiled(self.V, self.H, False)
+        self.lm_head_tiled = ops.tile_weights(self.w.lm_head) if self.lm_head_plan is not None else None
         m = self.tiled_max_m
         f32 = dict(dtype=torch.float32, device=self.device)
         self.part_qkv = torch.empty(plans["qkv"][1] * m * self.qw, **f32)
@@ -170,6 +172,13 @@ class ModelRunner:
             ops.linear_tiled(x, tw["gu"], 2 * self.F, out=act, tiles_per_wg=tg, epilogue=ops.EPI_SILU_MUL)
             ops.linear_tiled(act, tw["down"], self.H, partial=self.part_dn, tiles_per_wg=td, k_groups=gd, epilogue=P)
         ops.fused_add_rms_norm_partial(self.part_dn, gd, resid, self.w.final_norm, self.eps, x)
+
+    def lm_head_logits(self, x: torch.Tensor, out: torch.Tensor) -> None:
+        """Decode-step logits of the rows in x."""
+        if self.tiled is not None and self.lm_head_tiled is not None and x.shape[0] <= self.tiled_max_m:
+            ops.linear_tiled(x, self.lm_head_tiled, self.V, out=out, tiles_per_wg=self.lm_head_plan[0])
+        else:
+            torch.mm(x, self.w.lm_head.t(), out=out)
 
     def kv_cache_bytes_per_block(self) -> int:
         return 2 * self.L * self.nkv * BLOCK_SIZE * self.d * self.k_cache[0].element_size()
@@ -219,7 +228,7 @@ class ModelRunner:
         torch.index_select(self.w.embed, 0, ids, out=resid)
         if self.tiled is not None and b <= self.tiled_max_m:
             self._decode_layers_tiled(b, pos, slots, bt, ctx, splits)
-            torch.mm(x, self.w.lm_head.t(), out=self.logits[:b])
+            self.lm_head_logits(x, self.logits[:b])
             ops.argmax(self.logits[:b], out=self.next_ids[:b])
             return
 
@@ -232,7 +241,7 @@ class ModelRunner:
 
         last = self._layers(b, resid, x, qkv, attn, o, gu, act, dn, attend)
         ops.fused_add_rms_norm(last, resid, self.w.final_norm, self.eps, out=x)
-        torch.mm(x, self.w.lm_head.t(), out=self.logits[:b])
+        self.lm_head_logits(x, self.logits[:b])
         ops.argmax(self.logits[:b], out=self.next_ids[:b])
 
     def bucket_for(self, batch: int) -> int:
