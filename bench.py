@@ -145,11 +145,8 @@ def time_kernels(engine, batch, ctx_len):
     out["gemm_lm_head"] = timed(lambda i: r.lm_head_logits(x, r.logits[:b]), gemm(b, r.V, r.H))
 
     # attention over the live cache, at the context lengths of the last timed step
-    n64, n32 = r.host_inputs()
-    r.in64.copy_(r.h64)
-    r.in32.copy_(r.h32)
     splits = r._splits_for(b)
-    ctx_tokens = int(n32[:b].sum())
+    ctx_tokens = int(r.ctx[:b].sum().item())              # the device buffers still hold the last step's inputs
     kv_bytes = ctx_tokens * 2 * r.nkv * r.d * es + 2 * b * r.nh * r.d * es
     out["paged_attn_decode"] = timed(
         lambda i: ops.paged_attn_decode(qkv[:, : r.nh * r.d], r.k_cache[i], r.v_cache[i], r.block_tables[:b], r.ctx[:b],

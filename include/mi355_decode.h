@@ -291,6 +291,40 @@ int32_t mi355_rope_kv_write_partial(void* qkv, int64_t qkv_stride,
                                     int32_t num_kv_heads, int32_t head_dim,
                                     int32_t dtype, void* stream);
 
+/*
+ * mi355_linear_tiled with the neighbouring RMSNorm / residual-add / K-split
+ * reduction fused into the GEMM launch (tiles_per_wg 8 or 104 only):
+ *   norm_weight != NULL (epilogues 0-2): x is formed while it is staged,
+ *     x = round(round(x_in * inv_rms[row]) * norm_weight), inv_rms[row] =
+ *     rsqrt(sum_q norm_sumsq[q][row] / K + eps) with norm_sumsq fp32
+ *     [norm_parts][32] (what epilogue 4 of the previous GEMM wrote), added in a
+ *     fixed order.  x_in is the residual stream.
+ *   epilogue 3: K split over k_groups workgroups and reduced in the same launch:
+ *     y = round(partial[0] + ... + partial[k_groups-1] + bias).  Every workgroup
+ *     writes its slab and draws a ticket from counters[column group]; the one
+ *     drawing the last ticket adds the slabs in slab order, so the result does
+ *     not depend on scheduling, and nobody waits.  counters: uint32
+ *     [ceil(N / (16 * tiles))], zero before the first launch, left zero.
+ *   epilogue 4: as 3, then residual = round(y + residual) in place (y is not
+ *     stored) and sumsq_out[column group][row] = sum of residual^2 over the
+ *     column group (fp32 [ceil(N / (16 * tiles))][32]): the input of the next
+ *     GEMM's norm prologue.
+ * partial (fp32 [k_groups][M][N]) is scratch for epilogues 3 and 4.  Launches
+ * that share counters / partial must be ordered on one stream.  Replaces
+ * fused_add_rms_norm + the GEMM on either side of it (same engine operators as
+ * mi355_fused_add_rms_norm and mi355_linear_decode).
+ */
+int32_t mi355_linear_tiled_fused(void* y, int64_t y_stride, float* partial,
+                                 const void* x, int64_t x_stride,
+                                 const void* w_tiled, const void* bias,
+                                 int32_t M, int32_t N, int32_t K,
+                                 int32_t tiles_per_wg, int32_t k_groups,
+                                 int32_t epilogue, const void* norm_weight,
+                                 const float* norm_sumsq, int32_t norm_parts,
+                                 float eps, void* residual,
+                                 int64_t residual_stride, float* sumsq_out,
+                                 uint32_t* counters, int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

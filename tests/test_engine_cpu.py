@@ -45,12 +45,18 @@ class FakeRunner:
         self.V = V
         self.cache = np.full(num_blocks * 16, -1, dtype=np.int64)
         B = max_num_seqs
-        self.h64 = np.zeros(3 * B, dtype=np.int64)
-        self.h32 = np.zeros(B + B * self.max_blocks, dtype=np.int32)
+        self.h64s = [np.zeros(3 * B, dtype=np.int64) for _ in range(self.NUM_STAGES)]
+        self.h32s = [np.zeros(B + B * self.max_blocks, dtype=np.int32) for _ in range(self.NUM_STAGES)]
+        self.results = [None] * self.NUM_STAGES
+        self.dev_next = []                    # "device" copy of the last sampled tokens
         self.decode_batches, self.prefill_tokens = [], []
+        self.ahead_launches = 0
+        self.sampling_log = []
 
-    def host_inputs(self):
-        return self.h64, self.h32
+    NUM_STAGES = 2
+
+    def host_inputs(self, stage=0):
+        return self.h64s[stage], self.h32s[stage]
 
     def _context(self, bt_row, ctx):
         idx = np.arange(ctx)
@@ -58,11 +64,19 @@ class FakeRunner:
         assert (toks >= 0).all(), "read a slot that was never written"
         return toks.tolist()
 
-    def run_decode(self, n, sampling=None):
+    def launch_decode(self, n, stage=0, sampling=None, ids_from_device=False):
+        """Computes at once (the double has no queue) but hands the result over only in finish_decode."""
         self.last_sampling = sampling
+        self.sampling_log.append(sampling)
         B = self.max_num_seqs
-        ids, pos, slots = self.h64[:B], self.h64[B:2 * B], self.h64[2 * B:]
-        ctx, bt = self.h32[:B], self.h32[B:].reshape(B, self.max_blocks)
+        h64, h32 = self.h64s[stage], self.h32s[stage]
+        ids, pos, slots = h64[:B].copy(), h64[B:2 * B], h64[2 * B:]
+        if ids_from_device:
+            assert len(self.dev_next) >= n, "no previous step to take tokens from"
+            ids[:n] = self.dev_next[:n]
+            h64[:n] = -12345                  # the host copy of the ids must not be needed
+            self.ahead_launches += 1
+        ctx, bt = h32[:B], h32[B:].reshape(B, self.max_blocks)
         assert (slots[n:] == -1).all() and (ctx[n:] == 0).all(), "padding rows must be neutral"
         out = []
         for i in range(n):
@@ -70,6 +84,12 @@ class FakeRunner:
             self.cache[slots[i]] = ids[i]
             out.append(next_token(self._context(bt[i], int(ctx[i]))))
         self.decode_batches.append(n)
+        self.dev_next = list(out)
+        self.results[stage] = out
+
+    def finish_decode(self, n, stage=0):
+        out, self.results[stage] = self.results[stage], None
+        assert out is not None and len(out) == n
         return out
 
     def run_prefill(self, token_ids, positions, slot_mapping, block_tables, cu_seqlens, context_lens, max_q_len,
@@ -102,9 +122,9 @@ def run(engine):
     return got
 
 
-def make_engine(num_blocks=64, max_num_seqs=4, max_model_len=256, max_tokens=64, eos=None):
+def make_engine(num_blocks=64, max_num_seqs=4, max_model_len=256, max_tokens=64, eos=None, run_ahead=True):
     runner = FakeRunner(num_blocks, max_num_seqs, max_model_len)
-    return LLMEngine(runner, max_num_seqs, max_tokens, max_model_len, eos_token_ids=eos), runner
+    return LLMEngine(runner, max_num_seqs, max_tokens, max_model_len, eos_token_ids=eos, run_ahead=run_ahead), runner
 
 
 def prompts(n, rng, lo=1, hi=60):
@@ -242,8 +262,68 @@ def test_sampling_parameters_reach_the_runner():
     eng.step()                                                # prefill of "r"
     s = runner.last_sampling
     assert s["temperature"].tolist() == [np.float32(0.7)] and s["top_k"].tolist() == [5] and s["seeds"].tolist() == [42]
-    eng.step()                                                # decode of both
-    s = runner.last_sampling
+    eng.step()                                                # decode of both, and the step after it launched ahead
+    s, s_ahead = runner.sampling_log[-2:]
     assert s["temperature"].tolist() == [0.0, np.float32(0.7)] and s["steps"].tolist() == [1, 1]
+    assert s_ahead["steps"].tolist() == [2, 2] and s_ahead["seeds"].tolist() == s["seeds"].tolist()
     eng.add_request("u", [9], SamplingParams(max_tokens=2, temperature=1.0))      # no seed: engine draws one
     assert 0 <= eng.seqs["u"].seed < 2 ** 62
+
+
+def test_run_ahead_launches_no_step_that_length_limits_make_useless():
+    """One sequence, 20 tokens: the prefill samples the first, 19 decode steps the rest.
+    All but the first decode step are launched ahead of the host, and the engine does
+    not launch a 20th (it knows the sequence ends by length)."""
+    eng, runner = make_engine()
+    p = list(range(7))
+    eng.add_request("a", p, SamplingParams(max_tokens=20, temperature=0.0))
+    got = run(eng)
+    assert got["a"] == reference(p, 20)
+    assert len(runner.decode_batches) == 19 and runner.ahead_launches == 18
+    assert eng.stats["decode_steps"] == 19 and eng.stats["decode_tokens"] == 19
+
+
+def test_run_ahead_drops_the_token_computed_past_a_stop_token():
+    rng = np.random.default_rng(5)
+    p = rng.integers(0, V, size=11).tolist()
+    full = reference(p, 30)
+    stop = full[6]
+    cut = full.index(stop)
+    eng, runner = make_engine()
+    eng.add_request("a", p, SamplingParams(max_tokens=30, temperature=0.0, stop_token_ids=[stop]))
+    eng.add_request("b", p[:5], SamplingParams(max_tokens=30, temperature=0.0))
+    got = run(eng)
+    assert got["a"] == full[: cut + 1] and got["a:reason"] == "stop"
+    assert got["b"] == reference(p[:5], 30)                     # the other row of those steps is unaffected
+    assert eng.alloc.num_free == eng.alloc.num_blocks
+    assert eng.stats["decode_tokens"] == cut + 29               # the dropped token is not counted
+
+
+def test_run_ahead_on_and_off_generate_the_same_tokens():
+    rng = np.random.default_rng(6)
+    ps = prompts(9, rng)
+    outs = []
+    for ahead in (True, False):
+        eng, runner = make_engine(num_blocks=20, max_num_seqs=3, max_model_len=128, run_ahead=ahead)   # tight pool: preemptions
+        for i, p in enumerate(ps):
+            eng.add_request(f"r{i}", p, SamplingParams(max_tokens=25, temperature=0.0))
+        outs.append(run(eng))
+        assert (runner.ahead_launches > 0) == ahead
+        assert eng.alloc.num_free == 20
+    assert outs[0] == outs[1]
+    for i, p in enumerate(ps):
+        assert outs[0][f"r{i}"] == reference(p, 25)
+
+
+def test_abort_while_a_step_is_in_flight():
+    eng, _ = make_engine()
+    eng.add_request("a", list(range(30)), SamplingParams(max_tokens=40, temperature=0.0))
+    eng.add_request("b", list(range(12)), SamplingParams(max_tokens=10, temperature=0.0))
+    early = []
+    for _ in range(4):                                  # 2 prefills (token budget), then decode steps: one is now in flight
+        early += [t for o in eng.step() if o.request_id == "b" for t in o.new_token_ids]
+    assert eng._pending
+    eng.abort_request("a")
+    got = run(eng)
+    assert early + got["b"] == reference(list(range(12)), 10)
+    assert "a" not in got and eng.alloc.num_free == eng.alloc.num_blocks

@@ -583,3 +583,88 @@ def test_tiled_decode_chain_matches_plain_chain(ops):
     assert (np.abs(host(rd) - z_ref) <= 2 * ULP[dtype] * (np.abs(lin) + np.abs(z_ref))).all()
     d = np.abs(host(out) - y_ref)
     assert (d <= 4 * ULP[dtype] * np.abs(y_ref) + 1e-3).all()
+
+
+# --------------------------------------------------------------------------- #
+# GEMM launches with the K-split reduction / residual add / RMSNorm fused in
+# --------------------------------------------------------------------------- #
+def _groups(N, tiles):
+    return -(-((N + 15) // 16) // (tiles % 100))
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,N,K,tiles,groups,bias", [(32, 4096, 4096, 104, 4, False), (32, 4096, 14336, 104, 4, False),
+                                                     (9, 520, 2048, 104, 2, True), (32, 1024, 1024, 8, 1, True),
+                                                     (17, 6144, 4096, 104, 2, True), (1, 64, 512, 104, 1, False)])
+def test_linear_tiled_reduce_in_launch(ops, dtype, M, N, K, tiles, groups, bias):
+    """Epilogues 3 and 4: the slabs are added by the workgroup that finishes last, in slab
+    order -- bit-identical to adding the slabs of the partial-sum epilogue afterwards."""
+    rng = rng_for("tiled-reduce", dtype, M, N, K)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (N, K), dtype, 0.05)
+    b = grid(rng, (N,), dtype) if bias else None
+    res = grid(rng, (M, N), dtype)
+    wt, xd = ops.tile_weights(dev(w, dtype)), dev(x, dtype)
+    bd = dev(b, dtype) if bias else None
+    part = ops.linear_tiled(xd, wt, N, k_groups=groups, epilogue=ops.EPI_PARTIAL, tiles_per_wg=tiles).cpu().numpy()
+    y_ref = _slab_sum(part, b, dtype)
+    counters = torch.zeros(_groups(N, tiles), dtype=torch.int32, device="cuda")
+    for _ in range(2):                                   # the counters re-arm themselves
+        y = ops.linear_tiled_fused(xd, wt, N, tiles_per_wg=tiles, k_groups=groups, epilogue=ops.EPI_REDUCE_STORE,
+                                   bias=bd, counters=counters)
+        np.testing.assert_array_equal(host(y), y_ref)
+    assert int(counters.abs().sum()) == 0
+    ref64 = x.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
+    assert (np.abs(y_ref - ref64) <= _linear_tol(ref64, x, w, K, dtype)).all()
+
+    rd = dev(res, dtype)
+    sumsq = torch.full((_groups(N, tiles), 32), -1.0, dtype=torch.float32, device="cuda")
+    ops.linear_tiled_fused(xd, wt, N, tiles_per_wg=tiles, k_groups=groups, epilogue=ops.EPI_REDUCE_RESID, bias=bd,
+                           residual=rd, sumsq_out=sumsq, counters=counters)
+    z_ref = R.round_to(y_ref + res, dtype)
+    np.testing.assert_array_equal(host(rd), z_ref)
+    ss = sumsq.cpu().numpy()[:, :M].astype(np.float64).sum(0)
+    np.testing.assert_allclose(ss, (z_ref.astype(np.float64) ** 2).sum(1), rtol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,H,N2,tiles,epi", [(32, 4096, 6144, 104, "partial"), (32, 4096, 28672, 8, "silu"),
+                                              (5, 1024, 1000, 8, "store"), (20, 1024, 1536, 104, "partial")])
+def test_linear_tiled_norm_prologue(ops, dtype, M, H, N2, tiles, epi):
+    """A GEMM that leaves residual + sums of squares behind, then a GEMM that normalises the
+    residual while staging it == linear(rms_norm(residual)) of the oracle."""
+    rng = rng_for("tiled-norm", dtype, M, H, N2)
+    K1 = 1024
+    a, w1 = grid(rng, (M, K1), dtype), grid(rng, (H, K1), dtype, 0.05)
+    res0 = grid(rng, (M, H), dtype)
+    nw, w2 = R.round_to(1 + 0.1 * rng.standard_normal(H), dtype), grid(rng, (N2, H), dtype, 0.03)
+    b2 = grid(rng, (N2,), dtype) if epi == "store" else None
+    g1 = _groups(H, 104)
+    counters = torch.zeros(g1, dtype=torch.int32, device="cuda")
+    sumsq = torch.zeros(g1, 32, dtype=torch.float32, device="cuda")
+    rd = dev(res0, dtype)
+    ops.linear_tiled_fused(dev(a, dtype), ops.tile_weights(dev(w1, dtype)), H, tiles_per_wg=104, k_groups=2,
+                           epilogue=ops.EPI_REDUCE_RESID, residual=rd, sumsq_out=sumsq, counters=counters)
+    res = host(rd)                                       # checked bit-exactly by the test above
+    eps = 1e-5
+    xn = R.rms_norm(res, nw, eps, dtype)
+    kw = dict(tiles_per_wg=tiles, norm_weight=dev(nw, dtype), norm_sumsq=sumsq, norm_parts=g1, eps=eps)
+    if epi == "silu":
+        wt2 = ops.tile_weights(dev(w2, dtype), interleave_halves=True)
+        y = host(ops.linear_tiled_fused(rd, wt2, N2, epilogue=ops.EPI_SILU_MUL, **kw))
+        ref = R.silu_and_mul(R.linear(xn, w2, None, dtype), dtype)
+        diff = np.abs(y - ref)
+        assert (diff <= 6 * ULP[dtype] * np.abs(ref) + 6 * ULP[dtype] * 1e-2).all(), f"max diff {diff.max()}"
+        assert (diff > 0).mean() <= 0.05
+        return
+    wt2 = ops.tile_weights(dev(w2, dtype))
+    if epi == "partial":
+        part = ops.linear_tiled_fused(rd, wt2, N2, k_groups=2, epilogue=ops.EPI_PARTIAL, **kw).cpu().numpy()
+        y = _slab_sum(part, None, dtype)
+    else:
+        y = host(ops.linear_tiled_fused(rd, wt2, N2, epilogue=ops.EPI_STORE, bias=dev(b2, dtype), **kw))
+    ref64 = xn.astype(np.float64) @ w2.astype(np.float64).T + (b2.astype(np.float64) if b2 is not None else 0.0)
+    # a few normalised inputs may round the other way (another summation order of the squares)
+    tol = _linear_tol(ref64, xn, w2, H, dtype) + 4 * ULP[dtype] * np.abs(xn).max() * np.abs(w2).max()
+    err = np.abs(y - ref64)
+    assert (err <= tol).all(), f"max err {err.max()}"
+    assert (y != R.linear(xn, w2, b2, dtype)).mean() <= 0.05

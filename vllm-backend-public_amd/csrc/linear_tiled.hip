@@ -26,6 +26,17 @@
 //                 2u+1): act = round(round(silu(round(gate))) * round(up))
 //   EPI_PARTIAL   fp32 partial sums to slab [kgroup][M][N] (K split over
 //                 workgroups; the consumer kernel adds the slabs in order)
+//   EPI_REDUCE_STORE / EPI_REDUCE_RESID   K split over workgroups, finished in the
+//                 same launch: every workgroup writes its slab, then takes a ticket
+//                 from a per-column-group counter; the workgroup that draws the last
+//                 ticket adds the slabs in slab order (so the result does not depend
+//                 on which one that is) and writes y = round(sum + bias), or
+//                 residual = round(y + residual) together with the sum of squares of
+//                 its columns of each residual row.  Nobody waits for anybody.
+// Prologue NORM: x is not read as is but formed while it is staged,
+//   x = round(round(residual * inv_rms[row]) * norm_weight), inv_rms from the sums of
+//   squares the EPI_REDUCE_RESID epilogue of the previous GEMM left behind (added in
+//   a fixed order) -- the RMSNorm between two GEMMs costs no launch of its own.
 // HBM bytes: N*K*2 once; x is read from L2 once per workgroup.
 #include "common.h"
 
@@ -33,13 +44,26 @@ namespace mi355 {
 
 constexpr int kTU = 4;  // k-steps per register group
 
-enum { EPI_STORE = 0, EPI_SILU_MUL = 1, EPI_PARTIAL = 2 };
+enum { EPI_STORE = 0, EPI_SILU_MUL = 1, EPI_PARTIAL = 2, EPI_REDUCE_STORE = 3, EPI_REDUCE_RESID = 4 };
 
-template <typename T, int MT, int NW, int KSL, int EPI>
+constexpr int kSumsqRows = 32;  // row pitch of the sum-of-squares tables ([column group][32])
+
+struct FusedArgs {
+  const uint16_t* norm_w;    // prologue NORM: [K]
+  const float* sumsq_in;     //   [norm_parts][32] partial sums of squares of the rows of x
+  int norm_parts;
+  float eps;
+  uint16_t* resid;           // EPI_REDUCE_RESID: [M][N] in/out
+  int64_t resid_stride;
+  float* sumsq_out;          //   [gridDim.x][32]
+  unsigned* counters;        // EPI_REDUCE_*: [gridDim.x], zero before the first launch, left zero
+};
+
+template <typename T, int MT, int NW, int KSL, int EPI, bool NORM>
 __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
     uint16_t* __restrict__ y, float* __restrict__ partial, const uint16_t* __restrict__ x,
     const uint16_t* __restrict__ wt, const uint16_t* __restrict__ bias, int M, int N, int K,
-    int64_t x_stride, int64_t y_stride, int tiles_total, int phases_per_group) {
+    int64_t x_stride, int64_t y_stride, int tiles_total, int phases_per_group, FusedArgs fa) {
   constexpr int ROWS = MT * 16;
   constexpr int U = kTU;
   constexpr int NT = NW * 64;
@@ -48,6 +72,9 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   constexpr int G = KSL / 32 / U;          // register groups per phase (8 or 4)
   constexpr int D = 4;                     // ring depth
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * XBUF];
+  __shared__ float inv_s[NORM ? ROWS : 1];
+  __shared__ unsigned last_s;
+  static_assert(NT % (KSL / 8) == 0, "a thread must keep one column of the x slice");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -61,7 +88,9 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   // ---- x slice staging: 16-byte vectors, whole rows, coalesced
   constexpr int NX = ROWS * (KSL / 8) / NT;
   typedef unsigned int xvec __attribute__((ext_vector_type(4)));   // native vector: stays in registers
-  auto x_issue = [&](xvec (&xs)[NX], int p) {
+  // xs[NX] holds the slice; with NORM xs[NX] one more vector: the norm weights of this thread's column
+  constexpr int NXA = NX + (NORM ? 1 : 0);
+  auto x_issue = [&](xvec (&xs)[NXA], int p) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int v = i * NT + tid;
@@ -69,14 +98,28 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
       xs[i] = *reinterpret_cast<const xvec*>(x + static_cast<int64_t>(min(row, M - 1)) * x_stride +
                                              static_cast<int64_t>(p) * KSL + col * 8);
     }
+    if (NORM)
+      xs[NXA - 1] = *reinterpret_cast<const xvec*>(fa.norm_w + static_cast<int64_t>(p) * KSL + (tid % (KSL / 8)) * 8);
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto x_commit = [&](xvec (&xs)[NX], int buf) {
+  auto x_commit = [&](xvec (&xs)[NXA], int buf) {
+    float wn[8];
+    if (NORM) unpack8<T>(make_uint4(xs[NXA - 1].x, xs[NXA - 1].y, xs[NXA - 1].z, xs[NXA - 1].w), wn);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int v = i * NT + tid;
       const int row = v / (KSL / 8), col = v % (KSL / 8);
-      *reinterpret_cast<xvec*>(&lds[buf * XBUF + row * ROWB + col * 16]) = xs[i];
+      xvec o = xs[i];
+      if (NORM) {
+        float f[8];
+        unpack8<T>(make_uint4(o.x, o.y, o.z, o.w), f);
+        const float inv = inv_s[row];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = round_f<T>(f[j] * inv) * wn[j];
+        const uint4 q = pack8<T>(f);
+        o = xvec{q.x, q.y, q.z, q.w};
+      }
+      *reinterpret_cast<xvec*>(&lds[buf * XBUF + row * ROWB + col * 16]) = o;
     }
   };
 
@@ -111,14 +154,39 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
 #pragma unroll
   for (int j = 0; j < D - 1; ++j) load_group(ring[j], j);
   {
-    xvec xs0[NX];
+    xvec xs0[NXA];
     x_issue(xs0, p0);
+    if (NORM) {
+      // 1/rms of every row from the partial sums of squares: 8 threads per row, each adds
+      // every 8th part (8 loads in flight at a time), then a fixed-order butterfly
+      if (tid < ROWS * 8) {
+        const int row = tid >> 3, j = tid & 7;
+        float ss = 0.f;
+        if (row < M) {
+          for (int q0 = 0; q0 < fa.norm_parts; q0 += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int q = q0 + 8 * u + j;
+              v[u] = q < fa.norm_parts ? fa.sumsq_in[q * kSumsqRows + row] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ss += v[u];
+          }
+        }
+        ss += __shfl_xor(ss, 1);
+        ss += __shfl_xor(ss, 2);
+        ss += __shfl_xor(ss, 4);
+        if (j == 0) inv_s[row] = row < M ? 1.0f / sqrtf(ss / static_cast<float>(K) + fa.eps) : 0.f;
+      }
+      __syncthreads();
+    }
     x_commit(xs0, 0);
   }
   __syncthreads();
   for (int p = 0; p < P; ++p) {
     const bool more = p + 1 < P;
-    xvec xs[NX];                           // lives inside one iteration only
+    xvec xs[NXA];                          // lives inside one iteration only
     x_issue(xs, p0 + (more ? p + 1 : p));  // unconditional (the last phase re-loads its own slice, unused)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -168,6 +236,75 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
         for (int r = 0; r < 4; ++r)
           if (j0 + r < F) yp[r] = T::from_f(o[r]);
       }
+    }
+    return;
+  }
+  if (EPI == EPI_REDUCE_STORE || EPI == EPI_REDUCE_RESID) {
+    // The slabs cross workgroups (and XCDs, whose L2s are not coherent with each other)
+    // inside one launch.  They are written and read with device-scope atomic accesses,
+    // which go past the non-coherent cache levels one access at a time; a device-scope
+    // fence instead would write back and invalidate the whole L2 (measured: +35 us).
+    const int kgs = gridDim.y;
+    if (live) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int mm = 16 * m + c;
+        if (mm >= M) continue;
+        float* pp = partial + (static_cast<int64_t>(kgroup) * M + mm) * N + n0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n0 + r < N) __hip_atomic_store(pp + r, acc[m][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // every lane's slab stores have completed ...
+    __syncthreads();                                          // ... before one lane draws the ticket
+    if (tid == 0)
+      last_s = __hip_atomic_fetch_add(&fa.counters[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+               static_cast<unsigned>(kgs - 1);
+    __syncthreads();
+    if (!last_s) return;
+    if (tid == 0) fa.counters[blockIdx.x] = 0;   // all tickets drawn: re-arm for the next launch
+    // this workgroup's NW*16 columns, 8 per thread, NW*2 threads per row (M * NW*2 <= NT)
+    constexpr int VPR = NW * 2;
+    const int row = tid / VPR, col = blockIdx.x * (NW * 16) + (tid % VPR) * 8;
+    const bool on = row < M && col < N;       // N % 8 == 0 (checked on the host)
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = 0.f;
+    float ss = 0.f;
+    if (on) {
+      for (int s = 0; s < kgs; ++s) {
+        const float* p = partial + (static_cast<int64_t>(s) * M + row) * N + col;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __hip_atomic_load(p + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += v[j];
+      }
+      if (bias != nullptr) {
+        float bb[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(bias + col), bb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += bb[j];
+      }
+      if (EPI == EPI_REDUCE_RESID) {
+        uint4* rp = reinterpret_cast<uint4*>(fa.resid + static_cast<int64_t>(row) * fa.resid_stride + col);
+        float r[8];
+        unpack8<T>(*rp, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          f[j] = round_f<T>(round_f<T>(f[j]) + r[j]);
+          ss += f[j] * f[j];
+        }
+        *rp = pack8<T>(f);
+      } else {
+        *reinterpret_cast<uint4*>(y + static_cast<int64_t>(row) * y_stride + col) = pack8<T>(f);
+      }
+    }
+    if (EPI == EPI_REDUCE_RESID) {
+#pragma unroll
+      for (int d = 1; d < VPR; d <<= 1) ss += __shfl_xor(ss, d);
+      if (row < M && tid % VPR == 0) fa.sumsq_out[blockIdx.x * kSumsqRows + row] = ss;
     }
     return;
   }
@@ -231,30 +368,51 @@ __global__ void tile_weights_kernel(uint16_t* __restrict__ dst, const uint16_t* 
   }
 }
 
+#define MI355_LT_ARGS y, partial, x, wt, bias, M, N, K, xs, ys, tiles_total, ppg
+#define MI355_LT_PARAMS                                                                                       \
+  uint16_t *y, float *partial, const uint16_t *x, const uint16_t *wt, const uint16_t *bias, int M, int N, int K, \
+      int64_t xs, int64_t ys, int tiles_total, int ppg
+
+template <typename T, int MT, int NW, int KSL, int EPI, bool NORM>
+static void launch_one(dim3 grid, hipStream_t s, MI355_LT_PARAMS, const FusedArgs& fa) {
+  hipLaunchKernelGGL((linear_tiled_kernel<T, MT, NW, KSL, EPI, NORM>), grid, dim3(NW * 64), 0, s, MI355_LT_ARGS, fa);
+}
+
 template <typename T, int MT, int NW, int KSL>
-static void launch_epi(int epi, dim3 grid, hipStream_t s, uint16_t* y, float* partial, const uint16_t* x,
-                       const uint16_t* wt, const uint16_t* bias, int M, int N, int K, int64_t xs, int64_t ys,
-                       int tiles_total, int ppg) {
-  dim3 block(NW * 64);
-  if (epi == EPI_SILU_MUL)
-    hipLaunchKernelGGL((linear_tiled_kernel<T, MT, NW, KSL, EPI_SILU_MUL>), grid, block, 0, s, y, partial, x, wt, bias,
-                       M, N, K, xs, ys, tiles_total, ppg);
-  else if (epi == EPI_PARTIAL)
-    hipLaunchKernelGGL((linear_tiled_kernel<T, MT, NW, KSL, EPI_PARTIAL>), grid, block, 0, s, y, partial, x, wt, bias, M,
-                       N, K, xs, ys, tiles_total, ppg);
-  else
-    hipLaunchKernelGGL((linear_tiled_kernel<T, MT, NW, KSL, EPI_STORE>), grid, block, 0, s, y, partial, x, wt, bias, M, N,
-                       K, xs, ys, tiles_total, ppg);
+static void launch_epi(int epi, dim3 grid, hipStream_t s, MI355_LT_PARAMS) {
+  const FusedArgs none{};
+  if (epi == EPI_SILU_MUL) launch_one<T, MT, NW, KSL, EPI_SILU_MUL, false>(grid, s, MI355_LT_ARGS, none);
+  else if (epi == EPI_PARTIAL) launch_one<T, MT, NW, KSL, EPI_PARTIAL, false>(grid, s, MI355_LT_ARGS, none);
+  else launch_one<T, MT, NW, KSL, EPI_STORE, false>(grid, s, MI355_LT_ARGS, none);
 }
 
 template <typename T, int MT>
-static void launch_geom(int nw, int ksl, int epi, dim3 grid, hipStream_t s, uint16_t* y, float* partial,
-                        const uint16_t* x, const uint16_t* wt, const uint16_t* bias, int M, int N, int K,
-                        int64_t xs, int64_t ys, int tiles_total, int ppg) {
-  if (nw == 8 && ksl == 1024) launch_epi<T, MT, 8, 1024>(epi, grid, s, y, partial, x, wt, bias, M, N, K, xs, ys, tiles_total, ppg);
-  else if (nw == 8) launch_epi<T, MT, 8, 512>(epi, grid, s, y, partial, x, wt, bias, M, N, K, xs, ys, tiles_total, ppg);
-  else if (ksl == 1024) launch_epi<T, MT, 4, 1024>(epi, grid, s, y, partial, x, wt, bias, M, N, K, xs, ys, tiles_total, ppg);
-  else launch_epi<T, MT, 4, 512>(epi, grid, s, y, partial, x, wt, bias, M, N, K, xs, ys, tiles_total, ppg);
+static void launch_geom(int nw, int ksl, int epi, dim3 grid, hipStream_t s, MI355_LT_PARAMS) {
+  if (nw == 8 && ksl == 1024) launch_epi<T, MT, 8, 1024>(epi, grid, s, MI355_LT_ARGS);
+  else if (nw == 8) launch_epi<T, MT, 8, 512>(epi, grid, s, MI355_LT_ARGS);
+  else if (ksl == 1024) launch_epi<T, MT, 4, 1024>(epi, grid, s, MI355_LT_ARGS);
+  else launch_epi<T, MT, 4, 512>(epi, grid, s, MI355_LT_ARGS);
+}
+
+// The fused forms exist for the two geometries the decode step uses: 8 tiles x 1024-wide
+// slices (wide layers, unsplit) and 4 tiles x 512-wide slices (narrow layers, K split).
+template <typename T, int MT, int NW, int KSL>
+static void launch_fused_epi(int epi, bool norm, dim3 grid, hipStream_t s, MI355_LT_PARAMS, const FusedArgs& fa) {
+  if (norm) {
+    if (epi == EPI_SILU_MUL) launch_one<T, MT, NW, KSL, EPI_SILU_MUL, true>(grid, s, MI355_LT_ARGS, fa);
+    else if (epi == EPI_PARTIAL) launch_one<T, MT, NW, KSL, EPI_PARTIAL, true>(grid, s, MI355_LT_ARGS, fa);
+    else launch_one<T, MT, NW, KSL, EPI_STORE, true>(grid, s, MI355_LT_ARGS, fa);
+  } else if (epi == EPI_REDUCE_STORE) {
+    launch_one<T, MT, NW, KSL, EPI_REDUCE_STORE, false>(grid, s, MI355_LT_ARGS, fa);
+  } else {
+    launch_one<T, MT, NW, KSL, EPI_REDUCE_RESID, false>(grid, s, MI355_LT_ARGS, fa);
+  }
+}
+
+template <typename T, int MT>
+static void launch_fused(int nw, int epi, bool norm, dim3 grid, hipStream_t s, MI355_LT_PARAMS, const FusedArgs& fa) {
+  if (nw == 8) launch_fused_epi<T, MT, 8, 1024>(epi, norm, grid, s, MI355_LT_ARGS, fa);
+  else launch_fused_epi<T, MT, 4, 512>(epi, norm, grid, s, MI355_LT_ARGS, fa);
 }
 
 }  // namespace mi355
@@ -331,6 +489,78 @@ extern "C" int32_t mi355_linear_tiled(void* y, int64_t y_stride, void* partial, 
   } else {
     if (M <= 16) launch_geom<F16, 1>(nw, ksl, epilogue, grid, s, yp, pp, xp, wp, bp, M, N, K, x_stride, y_stride, tiles_total, ppg);
     else launch_geom<F16, 2>(nw, ksl, epilogue, grid, s, yp, pp, xp, wp, bp, M, N, K, x_stride, y_stride, tiles_total, ppg);
+  }
+  return check_launch(name);
+}
+
+extern "C" int32_t mi355_linear_tiled_fused(void* y, int64_t y_stride, float* partial, const void* x,
+                                            int64_t x_stride, const void* w_tiled, const void* bias, int32_t M,
+                                            int32_t N, int32_t K, int32_t tiles_per_wg, int32_t k_groups,
+                                            int32_t epilogue, const void* norm_weight, const float* norm_sumsq,
+                                            int32_t norm_parts, float eps, void* residual, int64_t residual_stride,
+                                            float* sumsq_out, uint32_t* counters, int32_t dtype, void* stream) {
+  using namespace mi355;
+  const char* name = "mi355_linear_tiled_fused";
+  const bool norm = norm_weight != nullptr;
+  const bool reduce = epilogue == EPI_REDUCE_STORE || epilogue == EPI_REDUCE_RESID;
+  if (!norm && !reduce)  // nothing fused: the plain entry point covers it
+    return mi355_linear_tiled(y, y_stride, partial, x, x_stride, w_tiled, bias, M, N, K, tiles_per_wg, k_groups,
+                              epilogue, dtype, stream);
+  MI355_REQUIRE(x && w_tiled, MI355_ERR_INVALID, "%s: null pointer", name);
+  MI355_REQUIRE(M >= 0 && M <= 32, MI355_ERR_UNSUPPORTED, "%s: M %d outside [0, 32]", name, M);
+  MI355_REQUIRE(epilogue >= EPI_STORE && epilogue <= EPI_REDUCE_RESID, MI355_ERR_INVALID, "%s: unknown epilogue %d",
+                name, epilogue);
+  MI355_REQUIRE(!(norm && reduce), MI355_ERR_UNSUPPORTED,
+                "%s: the norm prologue is built for epilogues 0-2, the reducing epilogues for plain x", name);
+  MI355_REQUIRE(tiles_per_wg == 8 || tiles_per_wg == 104, MI355_ERR_UNSUPPORTED,
+                "%s: fused forms exist for tiles_per_wg 8 (1024-wide slices) and 104 (512-wide)", name);
+  const int nw = tiles_per_wg % 100, ksl = tiles_per_wg >= 100 ? 512 : 1024;
+  MI355_REQUIRE(N > 0 && K > 0 && K % ksl == 0, MI355_ERR_UNSUPPORTED, "%s: K %d must be a multiple of %d", name, K, ksl);
+  const int phases = K / ksl;
+  MI355_REQUIRE(k_groups >= 1 && phases % k_groups == 0, MI355_ERR_INVALID, "%s: k_groups %d must divide K/%d = %d",
+                name, k_groups, ksl, phases);
+  MI355_REQUIRE(k_groups == 1 || epilogue == EPI_PARTIAL || reduce, MI355_ERR_INVALID,
+                "%s: k_groups > 1 needs a partial-sum or reducing epilogue", name);
+  MI355_REQUIRE(x_stride >= K && x_stride % 8 == 0 && aligned16(x) && aligned16(w_tiled), MI355_ERR_INVALID,
+                "%s: x/w_tiled must be 16-byte aligned, x_stride a multiple of 8", name);
+  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED,
+                "%s: dtype %d not supported (bf16/fp16 only)", name, dtype);
+  if (norm)
+    MI355_REQUIRE(norm_sumsq && norm_parts >= 1 && aligned16(norm_weight) && eps >= 0.f, MI355_ERR_INVALID,
+                  "%s: norm prologue needs norm_sumsq, norm_parts >= 1 and a 16-byte aligned weight", name);
+  if (epilogue == EPI_PARTIAL || reduce)
+    MI355_REQUIRE(partial && aligned16(partial), MI355_ERR_INVALID, "%s: partial buffer missing", name);
+  if (reduce) {
+    MI355_REQUIRE(counters && N % 8 == 0, MI355_ERR_INVALID, "%s: reducing epilogues need counters and N %% 8 == 0", name);
+    MI355_REQUIRE(bias == nullptr || aligned16(bias), MI355_ERR_INVALID, "%s: bias must be 16-byte aligned", name);
+  }
+  if (epilogue == EPI_REDUCE_RESID)
+    MI355_REQUIRE(residual && sumsq_out && aligned16(residual) && residual_stride >= N && residual_stride % 8 == 0,
+                  MI355_ERR_INVALID, "%s: residual (16-byte aligned, stride >= N, multiple of 8) and sumsq_out needed", name);
+  if (epilogue == EPI_STORE || epilogue == EPI_SILU_MUL || epilogue == EPI_REDUCE_STORE)
+    MI355_REQUIRE(y && y_stride >= (epilogue == EPI_SILU_MUL ? N / 2 : N) &&
+                      (epilogue != EPI_REDUCE_STORE || (aligned16(y) && y_stride % 8 == 0)),
+                  MI355_ERR_INVALID, "%s: y missing, misaligned or y_stride too small", name);
+  if (epilogue == EPI_SILU_MUL)
+    MI355_REQUIRE(N % 32 == 0 && bias == nullptr, MI355_ERR_UNSUPPORTED,
+                  "%s: SwiGLU epilogue needs N %% 32 == 0 and no bias", name);
+  if (M == 0) return MI355_OK;
+  const int tiles_total = (N + 15) / 16;
+  dim3 grid((tiles_total + nw - 1) / nw, k_groups);
+  FusedArgs fa{static_cast<const uint16_t*>(norm_weight), norm_sumsq, norm_parts, eps,
+               static_cast<uint16_t*>(residual), residual_stride, sumsq_out, counters};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  auto* yp = static_cast<uint16_t*>(y);
+  auto* xp = static_cast<const uint16_t*>(x);
+  auto* wp = static_cast<const uint16_t*>(w_tiled);
+  auto* bp = static_cast<const uint16_t*>(bias);
+  const int ppg = phases / k_groups;
+  if (dtype == MI355_BF16) {
+    if (M <= 16) launch_fused<BF16, 1>(nw, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K, x_stride, y_stride, tiles_total, ppg, fa);
+    else launch_fused<BF16, 2>(nw, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K, x_stride, y_stride, tiles_total, ppg, fa);
+  } else {
+    if (M <= 16) launch_fused<F16, 1>(nw, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K, x_stride, y_stride, tiles_total, ppg, fa);
+    else launch_fused<F16, 2>(nw, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K, x_stride, y_stride, tiles_total, ppg, fa);
   }
   return check_launch(name);
 }

@@ -8,6 +8,12 @@ prefilled (in chunks of at most ``max_num_batched_tokens``) and then every
 running sequence advances one token per decode step.  When the pool runs dry the
 youngest running sequence is preempted and later recomputed.
 
+Decode steps are launched asynchronously and the engine keeps one step ahead of
+the host: the step after the one in flight takes its input tokens on the device,
+so the GPU never waits for the host to read tokens, run the scheduler and stage
+inputs.  A sequence that stops on a token (EOS, stop id) is noticed one step
+late; the extra token computed for it is dropped.
+
 Under tensor parallelism every rank runs this same deterministic state machine
 on the same request stream, so all ranks issue identical steps and identical
 collectives without exchanging per-step metadata.
@@ -64,6 +70,7 @@ class Sequence:
     finish_reason: Optional[str] = None
     num_preemptions: int = 0
     seed: int = 0                    # sampling seed (request's, or drawn by the engine)
+    inflight: int = 0                # decode steps launched for this sequence and not yet harvested
 
     @property
     def all_ids(self) -> List[int]:
@@ -195,7 +202,7 @@ class LLMEngine:
     supports_random_sampling = True
 
     def __init__(self, runner, max_num_seqs: int, max_num_batched_tokens: int, max_model_len: int,
-                 eos_token_ids=None, seed: int = 0):
+                 eos_token_ids=None, seed: int = 0, run_ahead: bool = True):
         import random
         self._rng = random.Random(seed)          # same stream on every TP rank
         self.runner = runner
@@ -205,8 +212,12 @@ class LLMEngine:
         self.sched = Scheduler(self.alloc, max_num_seqs, max_num_batched_tokens, max_model_len)
         self.eos = set(eos_token_ids or [])
         self.seqs: Dict[str, Sequence] = {}
-        # host mirrors (numpy views of pinned memory) of the runner's packed decode inputs
-        self.n64, self.n32 = runner.host_inputs()
+        # host mirrors (numpy views of pinned memory) of the runner's packed decode inputs,
+        # one per staging set
+        self._hosts = [runner.host_inputs(i) for i in range(getattr(runner, "NUM_STAGES", 1))]
+        self._stage = 0
+        self._pending: deque = deque()        # decode steps launched and not yet harvested: (seqs, stage)
+        self.run_ahead = run_ahead and len(self._hosts) > 1
         self.stats = {"prefill_steps": 0, "decode_steps": 0, "prefill_tokens": 0, "decode_tokens": 0,
                       "preemptions": 0}
 
@@ -240,7 +251,7 @@ class LLMEngine:
             seq.finish_reason = seq.finish_reason or "abort"
 
     def has_unfinished(self) -> bool:
-        return bool(self.sched.waiting or self.sched.running)
+        return bool(self.sched.waiting or self.sched.running or self._pending)
 
     # ------------------------------------------------------------------ #
     def _append_token(self, seq: Sequence, tok: int, now: float) -> None:
@@ -271,7 +282,7 @@ class LLMEngine:
             "top_k": np.asarray([s.params.top_k for s in seqs], dtype=np.int32),
             "top_p": np.asarray([s.params.top_p for s in seqs], dtype=np.float32),
             "seeds": np.asarray([s.seed & 0x7FFFFFFFFFFFFFFF for s in seqs], dtype=np.int64),
-            "steps": np.asarray([len(s.output_ids) for s in seqs], dtype=np.int64),
+            "steps": np.asarray([len(s.output_ids) + s.inflight for s in seqs], dtype=np.int64),
         }
 
     def _output(self, seq: Sequence, new: List[int]) -> RequestOutput:
@@ -307,38 +318,82 @@ class LLMEngine:
                 outs.append(self._output(seq, [seq.output_ids[-1]]))
         return outs
 
-    def _decode(self, seqs: List[Sequence]) -> List[RequestOutput]:
+    # ------------------------------------------------------------------ #
+    # decode: launched asynchronously, at most one step ahead of the host
+    # ------------------------------------------------------------------ #
+    def _launch_decode(self, seqs: List[Sequence], ahead: bool) -> None:
+        """Stages and enqueues one decode step.  `ahead`: the step before it is still
+        in flight, so the input tokens are taken on the device from that step's
+        samples; everything else a step needs (positions, slots, pages) does not
+        depend on token values and is staged from the host as usual."""
         r = self.runner
         B, MB = r.max_num_seqs, r.max_blocks
         n = len(seqs)
-        n64, n32 = self.n64, self.n32
+        st = self._stage
+        self._stage = (st + 1) % len(self._hosts)
+        n64, n32 = self._hosts[st]
         n64[2 * B:] = -1                      # neutral padding: store nothing,
         n32[:B] = 0                           # attend to nothing
         bt = n32[B:].reshape(B, MB)
         for i, seq in enumerate(seqs):
-            p = seq.total_len - 1             # position of the last sampled token (not yet in the cache)
-            n64[i] = seq.output_ids[-1] if seq.output_ids else seq.prompt_ids[-1]
+            p = seq.total_len - 1 + seq.inflight   # position of the newest token (not yet in the cache)
+            if not ahead:
+                n64[i] = seq.output_ids[-1] if seq.output_ids else seq.prompt_ids[-1]
             n64[B + i] = p
             n64[2 * B + i] = seq.blocks[p // BLOCK_SIZE] * BLOCK_SIZE + p % BLOCK_SIZE
             n32[i] = p + 1
             bt[i, : len(seq.blocks)] = seq.blocks
-        toks = r.run_decode(n, sampling=self._sampling_arrays(seqs))
+        r.launch_decode(n, st, sampling=self._sampling_arrays(seqs), ids_from_device=ahead)
+        for seq in seqs:
+            seq.inflight += 1
+        self._pending.append((seqs, st))
+
+    def _try_launch_ahead(self, seqs: List[Sequence]) -> None:
+        """Launch the step after the one in flight if its batch is certain to be the
+        same rows: nobody waiting for admission, nobody ending by length at the step
+        in flight, a page available for every new token.  A row that ends on a stop
+        token at the step in flight computes one token too many, which is dropped."""
+        if not self.run_ahead or self.sched.waiting or len(seqs) != len(self.sched.running):
+            return
+        for s in seqs:
+            if (not s.blocks or len(s.output_ids) + s.inflight >= s.params.max_tokens
+                    or s.total_len + s.inflight >= self.max_model_len):
+                return
+        try:
+            for s in seqs:
+                self.sched._grow(s, s.total_len + s.inflight)
+        except NoFreeBlocks:
+            return
+        self._launch_decode(seqs, ahead=True)
+
+    def _harvest_decode(self) -> List[RequestOutput]:
+        seqs, st = self._pending.popleft()
+        toks = self.runner.finish_decode(len(seqs), st)
         now = time.perf_counter()
         self.stats["decode_steps"] += 1
-        self.stats["decode_tokens"] += n
         outs = []
         for seq, tok in zip(seqs, toks):
+            seq.inflight -= 1
+            if not seq.blocks:                # finished, aborted or preempted while the step was in flight
+                continue
+            self.stats["decode_tokens"] += 1
             seq.num_computed = seq.total_len
             self._append_token(seq, int(tok), now)
             outs.append(self._output(seq, [seq.output_ids[-1]]))
         return outs
 
     def step(self) -> List[RequestOutput]:
-        before = sum(s.num_preemptions for s in self.sched.running) + sum(s.num_preemptions for s in self.sched.waiting)
-        plan = self.sched.schedule()
-        if plan is None:
-            return []
-        after = sum(s.num_preemptions for s in self.sched.running) + sum(s.num_preemptions for s in self.sched.waiting)
-        self.stats["preemptions"] += after - before
-        kind, work = plan
-        return self._prefill(work) if kind == "prefill" else self._decode(work)
+        if not self._pending:
+            before = sum(s.num_preemptions for s in self.sched.running) + sum(s.num_preemptions for s in self.sched.waiting)
+            plan = self.sched.schedule()
+            if plan is None:
+                return []
+            after = sum(s.num_preemptions for s in self.sched.running) + sum(s.num_preemptions for s in self.sched.waiting)
+            self.stats["preemptions"] += after - before
+            kind, work = plan
+            if kind == "prefill":
+                return self._prefill(work)
+            self._launch_decode(work, ahead=False)
+        if len(self._pending) == 1:
+            self._try_launch_ahead(self._pending[0][0])
+        return self._harvest_decode()

@@ -53,6 +53,8 @@ def batch_buckets(max_num_seqs: int):
 
 
 class ModelRunner:
+    NUM_STAGES = 2
+
     def __init__(self, cfg: ModelConfig, weights: ModelWeights, dtype: torch.dtype, device,
                  num_blocks: int, max_num_seqs: int, max_model_len: int, tp_rank: int = 0,
                  tp_size: int = 1, tp_group=None, use_graphs: bool = True,
@@ -113,10 +115,14 @@ class ModelRunner:
         self.graphs = {}
         self.buckets = batch_buckets(B)
         self._init_tiled(tiled_linears)
-        # pinned host staging for the packed inputs and the sampled tokens
-        self.h64 = torch.zeros(3 * B, dtype=torch.int64).pin_memory()
-        self.h32 = torch.zeros(B + B * self.max_blocks, dtype=torch.int32).pin_memory()
-        self.h_next = torch.zeros(B, dtype=torch.int64).pin_memory()
+        # pinned host staging for the packed inputs and the sampled tokens: two sets, so
+        # that the host can stage step n+1 while step n is still running
+        self.h64s = [torch.zeros(3 * B, dtype=torch.int64).pin_memory() for _ in range(self.NUM_STAGES)]
+        self.h32s = [torch.zeros(B + B * self.max_blocks, dtype=torch.int32).pin_memory()
+                     for _ in range(self.NUM_STAGES)]
+        self.h_nexts = [torch.zeros(B, dtype=torch.int64).pin_memory() for _ in range(self.NUM_STAGES)]
+        self.done = [torch.cuda.Event() for _ in range(self.NUM_STAGES)]
+        self.h64, self.h32, self.h_next = self.h64s[0], self.h32s[0], self.h_nexts[0]
 
     # ------------------------------------------------------------------ #
     def _init_tiled(self, want: Optional[bool]) -> None:
@@ -287,9 +293,9 @@ class ModelRunner:
         self.graphs[bucket].replay()
         return self.next_ids[:batch]
 
-    def host_inputs(self):
-        """numpy views of the pinned staging buffers, laid out like in64 / in32."""
-        return self.h64.numpy(), self.h32.numpy()
+    def host_inputs(self, stage: int = 0):
+        """numpy views of one set of pinned staging buffers, laid out like in64 / in32."""
+        return self.h64s[stage].numpy(), self.h32s[stage].numpy()
 
     def _sample(self, logits: torch.Tensor, sampling: dict, out: torch.Tensor) -> None:
         """Re-draw the rows that asked for random sampling (greedy rows keep argmax)."""
@@ -299,19 +305,38 @@ class ModelRunner:
                    t(sampling["top_p"], torch.float32), t(sampling["seeds"], torch.int64),
                    t(sampling["steps"], torch.int64), out=out)
 
-    def run_decode(self, batch: int, sampling: Optional[dict] = None):
-        """Host-facing decode step: ships the staged inputs, replays the step and
-        returns the sampled token ids as a Python list (one stream sync).
-        `sampling` (numpy arrays temperature/top_k/top_p/seeds/steps, one entry per
-        row) is given only when some row is not greedy."""
-        self.in64.copy_(self.h64, non_blocking=True)
-        self.in32.copy_(self.h32, non_blocking=True)
+    def launch_decode(self, batch: int, stage: int = 0, sampling: Optional[dict] = None,
+                      ids_from_device: bool = False) -> None:
+        """Enqueues one decode step on the current stream and returns at once: ships
+        staging set `stage`, replays the step, copies the sampled ids to the set's
+        pinned result buffer.  With `ids_from_device` the input token of row i is
+        the token row i sampled in the step launched before this one (it never
+        leaves the GPU), and only positions, slots, context lengths and block tables
+        come from the host: the host can launch step n+1 before it has seen the
+        tokens of step n.  `sampling` (numpy arrays temperature/top_k/top_p/seeds/
+        steps, one entry per row) is given only when some row is not greedy."""
+        B = self.max_num_seqs
+        if ids_from_device:
+            self.in64[B:].copy_(self.h64s[stage][B:], non_blocking=True)
+            self.ids[:batch].copy_(self.next_ids[:batch], non_blocking=True)
+        else:
+            self.in64.copy_(self.h64s[stage], non_blocking=True)
+        self.in32.copy_(self.h32s[stage], non_blocking=True)
         nxt = self.decode(batch)
         if sampling is not None:
             self._sample(self.logits[:batch], sampling, nxt)
-        self.h_next[:batch].copy_(nxt, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        return self.h_next[:batch].tolist()
+        self.h_nexts[stage][:batch].copy_(nxt, non_blocking=True)
+        self.done[stage].record()
+
+    def finish_decode(self, batch: int, stage: int = 0):
+        """Waits for the step launched on `stage`; returns its sampled ids as a list."""
+        self.done[stage].synchronize()
+        return self.h_nexts[stage][:batch].tolist()
+
+    def run_decode(self, batch: int, sampling: Optional[dict] = None):
+        """One synchronous decode step over staging set 0."""
+        self.launch_decode(batch, 0, sampling)
+        return self.finish_decode(batch, 0)
 
     def run_prefill(self, token_ids, positions, slot_mapping, block_tables, cu_seqlens, context_lens,
                     max_q_len: int, sampling: Optional[dict] = None):

@@ -277,7 +277,8 @@ def sample(logits: torch.Tensor, temperature: torch.Tensor, top_k: torch.Tensor,
     return out
 
 
-EPI_STORE, EPI_SILU_MUL, EPI_PARTIAL = 0, 1, 2
+EPI_STORE, EPI_SILU_MUL, EPI_PARTIAL, EPI_REDUCE_STORE, EPI_REDUCE_RESID = 0, 1, 2, 3, 4
+SUMSQ_ROWS = 32                      # row pitch of the sum-of-squares tables
 LINEAR_TILED_MAX_M = 32
 LINEAR_TILED_K_MULTIPLE = 1024       # (512 with the 104/108 geometries)
 
@@ -285,24 +286,24 @@ LINEAR_TILED_K_MULTIPLE = 1024       # (512 with the 104/108 geometries)
 def plan_linear_tiled(N: int, K: int, split_k: bool):
     """(tiles_per_wg, k_groups) for linear_tiled on an [N, K] weight, or None when the
     kernel does not cover the shape.  One workgroup per CU (>= ~192 workgroups) is what
-    saturates the weight stream: wide layers take 8 tiles per workgroup unsplit; narrow
-    ones (N/16/4 < 192 workgroups) split K over workgroups when the caller can consume
-    fp32 partial sums, using 512-wide x slices so two workgroups share a CU."""
+    saturates the weight stream: wide layers take 8 tiles per workgroup and 1024-wide x
+    slices, unsplit; narrower ones take 4 tiles and 512-wide slices (two workgroups per
+    CU) and, when the caller can consume or reduce fp32 partial sums, split K over
+    workgroups until there are enough of them."""
     if K % 512:
         return None
     tiles_total = (N + 15) // 16
-    if not split_k or tiles_total >= 8 * 160:
-        if K % 1024:
-            return (104 if tiles_total < 8 * 160 else 108), 1
-        return (8 if tiles_total >= 8 * 160 else 4), 1
-    wgs = -(-tiles_total // 4)
-    phases = K // 512
+    if tiles_total >= 8 * 160 and K % 1024 == 0:
+        return 8, 1
     groups = 1
-    for g in (1, 2, 4, 7, 8):
-        if phases % g == 0:
-            groups = g
-            if wgs * g >= 192:
-                break
+    if split_k:
+        wgs = -(-tiles_total // 4)
+        phases = K // 512
+        for g in (1, 2, 4, 7, 8):
+            if phases % g == 0:
+                groups = g
+                if wgs * g >= 192:
+                    break
     return 104, groups
 
 
@@ -355,3 +356,60 @@ def linear_tiled(x: torch.Tensor, w_tiled: torch.Tensor, N: int, bias: torch.Ten
                                  bias.data_ptr() if bias is not None else 0, M, N, K, tiles_per_wg, k_groups,
                                  epilogue, dt, _stream()))
     return ret
+
+
+def linear_tiled_fused(x: torch.Tensor, w_tiled: torch.Tensor, N: int, *, tiles_per_wg: int, k_groups: int = 1,
+                       epilogue: int = EPI_STORE, bias: torch.Tensor | None = None, out: torch.Tensor | None = None,
+                       partial: torch.Tensor | None = None, norm_weight: torch.Tensor | None = None,
+                       norm_sumsq: torch.Tensor | None = None, norm_parts: int = 0, eps: float = 0.0,
+                       residual: torch.Tensor | None = None, sumsq_out: torch.Tensor | None = None,
+                       counters: torch.Tensor | None = None):
+    """linear_tiled with the RMSNorm before it (norm_weight + norm_sumsq: x is the residual
+    stream, normalised while it is staged) and/or the K-split reduction, residual add and
+    sum of squares after it (epilogues EPI_REDUCE_STORE / EPI_REDUCE_RESID) in the same launch."""
+    dt = _dt16(x, "x")
+    _dev(w_tiled, "w_tiled")
+    M, K = x.shape
+    if w_tiled.dtype != x.dtype or w_tiled.numel() != int(lib.mi355_tiled_weight_elems(N, K)):
+        raise ValueError("w_tiled does not match (N, K) / dtype")
+    nw = tiles_per_wg % 100
+    groups = -(-((N + 15) // 16) // max(nw, 1))
+    y_ptr, y_stride = 0, 0
+    if epilogue in (EPI_STORE, EPI_SILU_MUL, EPI_REDUCE_STORE):
+        width = N // 2 if epilogue == EPI_SILU_MUL else N
+        if out is None:
+            out = torch.empty((M, width), dtype=x.dtype, device=x.device)
+        elif out.dtype != x.dtype or tuple(out.shape) != (M, width):
+            raise ValueError(f"out must be [M, {width}] in the dtype of x")
+        y_ptr, y_stride = out.data_ptr(), _rows(out, "out")
+    if epilogue in (EPI_PARTIAL, EPI_REDUCE_STORE, EPI_REDUCE_RESID):
+        if partial is None:
+            partial = torch.empty((k_groups, M, N), dtype=torch.float32, device=x.device)
+        _check_partial(partial, k_groups, M, N)
+    if epilogue in (EPI_REDUCE_STORE, EPI_REDUCE_RESID):
+        if counters is None or counters.dtype != torch.int32 or counters.numel() < groups or not counters.is_cuda:
+            raise ValueError(f"counters must be a zero-initialised int32 device tensor with >= {groups} elements")
+    if epilogue == EPI_REDUCE_RESID:
+        if residual is None or residual.dtype != x.dtype or tuple(residual.shape) != (M, N):
+            raise ValueError("residual must be [M, N] in the dtype of x")
+        if (sumsq_out is None or sumsq_out.dtype != torch.float32 or sumsq_out.numel() < groups * SUMSQ_ROWS
+                or not sumsq_out.is_contiguous()):
+            raise ValueError(f"sumsq_out must be contiguous float32 with >= {groups} x {SUMSQ_ROWS} elements")
+    if norm_weight is not None:
+        if norm_weight.dtype != x.dtype or norm_weight.numel() != K or not norm_weight.is_contiguous():
+            raise ValueError("norm_weight must be contiguous [K] in the dtype of x")
+        if (norm_sumsq is None or norm_sumsq.dtype != torch.float32 or norm_parts < 1
+                or norm_sumsq.numel() < norm_parts * SUMSQ_ROWS or not norm_sumsq.is_contiguous()):
+            raise ValueError("norm_sumsq must be contiguous float32 [norm_parts, 32]")
+    if bias is not None and (bias.dtype != x.dtype or bias.numel() != N or not bias.is_contiguous()):
+        raise ValueError("bias must be contiguous [N] in the dtype of x")
+    ptr = lambda t: t.data_ptr() if t is not None else 0  # noqa: E731
+    check(lib.mi355_linear_tiled_fused(
+        y_ptr, y_stride, ptr(partial), x.data_ptr(), _rows(x, "x"), w_tiled.data_ptr(), ptr(bias), M, N, K,
+        tiles_per_wg, k_groups, epilogue, ptr(norm_weight), ptr(norm_sumsq), norm_parts, float(eps), ptr(residual),
+        _rows(residual, "residual") if residual is not None else 0, ptr(sumsq_out), ptr(counters), dt, _stream()))
+    if epilogue == EPI_PARTIAL:
+        return partial
+    if epilogue == EPI_REDUCE_RESID:
+        return residual
+    return out
