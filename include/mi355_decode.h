@@ -233,13 +233,16 @@ int32_t mi355_tile_weights(void* dst, const void* src, int32_t N, int32_t K,
                            int32_t interleave_halves, void* stream);
 
 /*
- * Decode-time linear layer on fragment-tiled weights, M <= 32:
+ * Decode-time linear layer on fragment-tiled weights, M <= 128:
  * y[M, N] = x[M, K] . W[N, K]^T.  Every weight load is 1 KB of contiguous memory
  * and each wave streams one 16-row tile of W; x is staged through LDS once per
- * workgroup.  tiles_per_wg = 4 or 8 tiles (= waves) per workgroup with 1024-wide
- * x slices (K % 1024 == 0), or 104 / 108 for the same with 512-wide slices
- * (K % 512 == 0, two workgroups per CU); k_groups splits K over workgroups and
- * must divide the slice count.
+ * workgroup, one K slice at a time.  tiles_per_wg = 4 or 8 tiles (= waves) per
+ * workgroup with wide x slices, or 104 / 108 for the same with narrow slices (two
+ * workgroups per CU).  Slice width: 1024 (narrow 512) for M <= 32, halved for
+ * M <= 64 and again for M <= 128; K must be a multiple of it, and with 256-wide
+ * slices every workgroup needs an even number of them.  Built geometries:
+ * M <= 32: 4, 8, 104, 108; M <= 64: 8, 104; M <= 128: 8.  k_groups splits K over
+ * workgroups and must divide the slice count.
  *   epilogue 0: y = round(sum + bias)                       (k_groups == 1)
  *   epilogue 1: weights tiled with interleave_halves; y[M, N/2] =
  *               round(round(silu(round(gate))) * round(up))  (k_groups == 1)
@@ -293,7 +296,8 @@ int32_t mi355_rope_kv_write_partial(void* qkv, int64_t qkv_stride,
 
 /*
  * mi355_linear_tiled with the neighbouring RMSNorm / residual-add / K-split
- * reduction fused into the GEMM launch (tiles_per_wg 8 or 104 only):
+ * reduction fused into the GEMM launch (tiles_per_wg 8 or 104 for M <= 64, 8
+ * beyond; norm prologue and epilogue 4: M <= 32):
  *   norm_weight != NULL (epilogues 0-2): x is formed while it is staged,
  *     x = round(round(x_in * inv_rms[row]) * norm_weight), inv_rms[row] =
  *     rsqrt(sum_q norm_sumsq[q][row] / K + eps) with norm_sumsq fp32

@@ -668,3 +668,64 @@ def test_linear_tiled_norm_prologue(ops, dtype, M, H, N2, tiles, epi):
     err = np.abs(y - ref64)
     assert (err <= tol).all(), f"max err {err.max()}"
     assert (y != R.linear(xn, w2, b2, dtype)).mean() <= 0.05
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,N,K,tiles,groups", [(64, 4096, 4096, 104, 4), (33, 1000, 1024, 8, 1), (64, 6144, 4096, 8, 1),
+                                                (128, 4096, 14336, 8, 7), (100, 1536, 4096, 8, 8), (65, 320, 512, 8, 1),
+                                                (128, 28672, 4096, 8, 1), (48, 4096, 1024, 104, 2)])
+def test_linear_tiled_up_to_128_rows(ops, dtype, M, N, K, tiles, groups):
+    """33..128 rows (more m-tiles per wave, narrower x slices): store, partial slabs and the
+    in-launch reduction against the fp64 product; the reduction bit-identical to the slab sum."""
+    rng = rng_for("tiled-rows", dtype, M, N, K)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (N, K), dtype, 0.05)
+    wt, xd = ops.tile_weights(dev(w, dtype)), dev(x, dtype)
+    ref64 = x.astype(np.float64) @ w.astype(np.float64).T
+    tol = _linear_tol(ref64, x, w, K, dtype)
+    if groups == 1:
+        y = host(ops.linear_tiled(xd, wt, N, tiles_per_wg=tiles))
+        assert (np.abs(y - ref64) <= tol).all()
+        assert (y != R.linear(x, w, None, dtype)).mean() <= 0.02
+        y0 = host(ops.linear_tiled(xd, wt, N))                       # geometry chosen by the wrapper
+        assert (np.abs(y0 - ref64) <= tol).all()
+    part = ops.linear_tiled(xd, wt, N, k_groups=groups, epilogue=ops.EPI_PARTIAL, tiles_per_wg=tiles).cpu().numpy()
+    kg = K // groups
+    for g in range(groups):
+        ref = x[:, g * kg:(g + 1) * kg].astype(np.float64) @ w[:, g * kg:(g + 1) * kg].astype(np.float64).T
+        np.testing.assert_allclose(part[g], ref, rtol=1e-4, atol=2e-3)
+    y_ref = _slab_sum(part, None, dtype)
+    assert (np.abs(y_ref - ref64) <= tol).all()
+    if N % 8 == 0:
+        counters = torch.zeros(_groups(N, tiles), dtype=torch.int32, device="cuda")
+        for _ in range(2):
+            y = ops.linear_tiled_fused(xd, wt, N, tiles_per_wg=tiles, k_groups=groups, epilogue=ops.EPI_REDUCE_STORE,
+                                       counters=counters)
+            np.testing.assert_array_equal(host(y), y_ref)
+
+
+@pytest.mark.parametrize("M,F,K", [(64, 14336, 4096), (128, 14336, 4096), (40, 512, 1024), (128, 64, 512)])
+def test_linear_tiled_swiglu_epilogue_up_to_128_rows(ops, M, F, K):
+    dtype = "bfloat16"
+    rng = rng_for("tiled-silu-rows", M, F, K)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (2 * F, K), dtype, 0.05)
+    xd = dev(x, dtype)
+    y = host(ops.linear_tiled(xd, ops.tile_weights(dev(w, dtype), interleave_halves=True), 2 * F,
+                              epilogue=ops.EPI_SILU_MUL))
+    gu = ops.linear_tiled(xd, ops.tile_weights(dev(w, dtype)), 2 * F)
+    np.testing.assert_array_equal(y, host(ops.silu_and_mul(gu)))
+    ref = R.silu_and_mul(R.linear(x, w, None, dtype), dtype)
+    diff = np.abs(y - ref)
+    assert (diff <= 4 * ULP[dtype] * np.abs(ref) + 4 * ULP[dtype] * 1e-2).all()
+
+
+def test_linear_tiled_rejects_unbuilt_geometries(ops):
+    from mi355_decode._lib import Mi355Error
+    x = torch.zeros(128, 1024, dtype=torch.bfloat16, device="cuda")
+    wt = ops.tile_weights(torch.zeros(64, 1024, dtype=torch.bfloat16, device="cuda"))
+    with pytest.raises(Mi355Error, match="no kernel for M 128"):
+        ops.linear_tiled(x, wt, 64, tiles_per_wg=4)
+    with pytest.raises(Mi355Error, match="even number"):
+        ops.linear_tiled(x[:, :768].contiguous(), ops.tile_weights(torch.zeros(64, 768, dtype=torch.bfloat16, device="cuda")),
+                         64, tiles_per_wg=8)
+    with pytest.raises(Mi355Error, match="outside"):
+        ops.linear_tiled(torch.zeros(129, 1024, dtype=torch.bfloat16, device="cuda"), wt, 64)

@@ -1,4 +1,4 @@
-// Decode-time linear layer on FRAGMENT-TILED weights:  y[M, N] = x[M, K] . W[N, K]^T, M <= 32.
+// Decode-time linear layer on FRAGMENT-TILED weights:  y[M, N] = x[M, K] . W[N, K]^T, M <= 128.
 //
 // Weight layout (built once at load time, mi355_tile_weights): W is cut into
 // blocks of 16 rows x 32 k; block (tile, kstep) is 1 KB stored as
@@ -69,8 +69,12 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   constexpr int NT = NW * 64;
   constexpr int ROWB = KSL * 2 + 32;       // padded LDS row (bytes)
   constexpr int XBUF = ROWS * ROWB;
-  constexpr int G = KSL / 32 / U;          // register groups per phase (8 or 4)
+  constexpr int G = KSL / 32 / U;          // register groups per phase (8, 4 or 2)
   constexpr int D = 4;                     // ring depth
+  constexpr int PU = G >= D ? 1 : D / G;   // phases per main-loop iteration: ring slots stay compile-time
+  static_assert((PU * G) % D == 0, "ring slots must repeat every main-loop iteration");
+  static_assert(!NORM || MT <= 2, "the norm prologue is built for M <= 32");
+  static_assert(EPI != EPI_REDUCE_RESID || MT <= 2, "the sum-of-squares table has 32 rows");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * XBUF];
   __shared__ float inv_s[NORM ? ROWS : 1];
   __shared__ unsigned last_s;
@@ -184,18 +188,22 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
     x_commit(xs0, 0);
   }
   __syncthreads();
-  for (int p = 0; p < P; ++p) {
-    const bool more = p + 1 < P;
-    xvec xs[NXA];                          // lives inside one iteration only
-    x_issue(xs, p0 + (more ? p + 1 : p));  // unconditional (the last phase re-loads its own slice, unused)
+  for (int p = 0; p < P; p += PU) {        // P % PU == 0 (checked on the host)
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      load_group(ring[(g + D - 1) % D], p * G + g + D - 1);
-      compute(ring[g % D], p & 1, g);
-    }
-    if (more) {
-      x_commit(xs, (p + 1) & 1);
-      __syncthreads();
+    for (int pp = 0; pp < PU; ++pp) {
+      const int q = p + pp;
+      const bool more = q + 1 < P;
+      xvec xs[NXA];                          // lives inside one phase only
+      x_issue(xs, p0 + (more ? q + 1 : q));  // unconditional (the last phase re-loads its own slice, unused)
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        load_group(ring[(pp * G + g + D - 1) % D], q * G + g + D - 1);
+        compute(ring[(pp * G + g) % D], q & 1, g);
+      }
+      if (more) {
+        x_commit(xs, (q + 1) & 1);
+        __syncthreads();
+      }
     }
   }
 
@@ -264,47 +272,49 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
     __syncthreads();
     if (!last_s) return;
     if (tid == 0) fa.counters[blockIdx.x] = 0;   // all tickets drawn: re-arm for the next launch
-    // this workgroup's NW*16 columns, 8 per thread, NW*2 threads per row (M * NW*2 <= NT)
+    // this workgroup's NW*16 columns, 8 per thread, NW*2 threads per row, NT / (NW*2) = 32 rows per pass
     constexpr int VPR = NW * 2;
-    const int row = tid / VPR, col = blockIdx.x * (NW * 16) + (tid % VPR) * 8;
-    const bool on = row < M && col < N;       // N % 8 == 0 (checked on the host)
-    float f[8];
+    const int col = blockIdx.x * (NW * 16) + (tid % VPR) * 8;
+    for (int row = tid / VPR; row < ROWS; row += NT / VPR) {   // same trip count for every lane (shuffles below)
+      const bool on = row < M && col < N;       // N % 8 == 0 (checked on the host)
+      float f[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = 0.f;
-    float ss = 0.f;
-    if (on) {
-      for (int s = 0; s < kgs; ++s) {
-        const float* p = partial + (static_cast<int64_t>(s) * M + row) * N + col;
-        float v[8];
+      for (int j = 0; j < 8; ++j) f[j] = 0.f;
+      float ss = 0.f;
+      if (on) {
+        for (int s = 0; s < kgs; ++s) {
+          const float* p = partial + (static_cast<int64_t>(s) * M + row) * N + col;
+          float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = __hip_atomic_load(p + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int j = 0; j < 8; ++j) v[j] = __hip_atomic_load(p + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] += v[j];
-      }
-      if (bias != nullptr) {
-        float bb[8];
-        unpack8<T>(*reinterpret_cast<const uint4*>(bias + col), bb);
+          for (int j = 0; j < 8; ++j) f[j] += v[j];
+        }
+        if (bias != nullptr) {
+          float bb[8];
+          unpack8<T>(*reinterpret_cast<const uint4*>(bias + col), bb);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] += bb[j];
+          for (int j = 0; j < 8; ++j) f[j] += bb[j];
+        }
+        if (EPI == EPI_REDUCE_RESID) {
+          uint4* rp = reinterpret_cast<uint4*>(fa.resid + static_cast<int64_t>(row) * fa.resid_stride + col);
+          float r[8];
+          unpack8<T>(*rp, r);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            f[j] = round_f<T>(round_f<T>(f[j]) + r[j]);
+            ss += f[j] * f[j];
+          }
+          *rp = pack8<T>(f);
+        } else {
+          *reinterpret_cast<uint4*>(y + static_cast<int64_t>(row) * y_stride + col) = pack8<T>(f);
+        }
       }
       if (EPI == EPI_REDUCE_RESID) {
-        uint4* rp = reinterpret_cast<uint4*>(fa.resid + static_cast<int64_t>(row) * fa.resid_stride + col);
-        float r[8];
-        unpack8<T>(*rp, r);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          f[j] = round_f<T>(round_f<T>(f[j]) + r[j]);
-          ss += f[j] * f[j];
-        }
-        *rp = pack8<T>(f);
-      } else {
-        *reinterpret_cast<uint4*>(y + static_cast<int64_t>(row) * y_stride + col) = pack8<T>(f);
+        for (int d = 1; d < VPR; d <<= 1) ss += __shfl_xor(ss, d);
+        if (row < M && tid % VPR == 0) fa.sumsq_out[blockIdx.x * kSumsqRows + row] = ss;
       }
-    }
-    if (EPI == EPI_REDUCE_RESID) {
-#pragma unroll
-      for (int d = 1; d < VPR; d <<= 1) ss += __shfl_xor(ss, d);
-      if (row < M && tid % VPR == 0) fa.sumsq_out[blockIdx.x * kSumsqRows + row] = ss;
     }
     return;
   }
@@ -378,41 +388,124 @@ static void launch_one(dim3 grid, hipStream_t s, MI355_LT_PARAMS, const FusedArg
   hipLaunchKernelGGL((linear_tiled_kernel<T, MT, NW, KSL, EPI, NORM>), grid, dim3(NW * 64), 0, s, MI355_LT_ARGS, fa);
 }
 
-template <typename T, int MT, int NW, int KSL>
-static void launch_epi(int epi, dim3 grid, hipStream_t s, MI355_LT_PARAMS) {
-  const FusedArgs none{};
-  if (epi == EPI_SILU_MUL) launch_one<T, MT, NW, KSL, EPI_SILU_MUL, false>(grid, s, MI355_LT_ARGS, none);
-  else if (epi == EPI_PARTIAL) launch_one<T, MT, NW, KSL, EPI_PARTIAL, false>(grid, s, MI355_LT_ARGS, none);
-  else launch_one<T, MT, NW, KSL, EPI_STORE, false>(grid, s, MI355_LT_ARGS, none);
-}
-
-template <typename T, int MT>
-static void launch_geom(int nw, int ksl, int epi, dim3 grid, hipStream_t s, MI355_LT_PARAMS) {
-  if (nw == 8 && ksl == 1024) launch_epi<T, MT, 8, 1024>(epi, grid, s, MI355_LT_ARGS);
-  else if (nw == 8) launch_epi<T, MT, 8, 512>(epi, grid, s, MI355_LT_ARGS);
-  else if (ksl == 1024) launch_epi<T, MT, 4, 1024>(epi, grid, s, MI355_LT_ARGS);
-  else launch_epi<T, MT, 4, 512>(epi, grid, s, MI355_LT_ARGS);
-}
-
-// The fused forms exist for the two geometries the decode step uses: 8 tiles x 1024-wide
-// slices (wide layers, unsplit) and 4 tiles x 512-wide slices (narrow layers, K split).
-template <typename T, int MT, int NW, int KSL>
-static void launch_fused_epi(int epi, bool norm, dim3 grid, hipStream_t s, MI355_LT_PARAMS, const FusedArgs& fa) {
-  if (norm) {
-    if (epi == EPI_SILU_MUL) launch_one<T, MT, NW, KSL, EPI_SILU_MUL, true>(grid, s, MI355_LT_ARGS, fa);
-    else if (epi == EPI_PARTIAL) launch_one<T, MT, NW, KSL, EPI_PARTIAL, true>(grid, s, MI355_LT_ARGS, fa);
-    else launch_one<T, MT, NW, KSL, EPI_STORE, true>(grid, s, MI355_LT_ARGS, fa);
-  } else if (epi == EPI_REDUCE_STORE) {
-    launch_one<T, MT, NW, KSL, EPI_REDUCE_STORE, false>(grid, s, MI355_LT_ARGS, fa);
-  } else {
-    launch_one<T, MT, NW, KSL, EPI_REDUCE_RESID, false>(grid, s, MI355_LT_ARGS, fa);
+// Which (epilogue, prologue) combinations exist for a geometry.  PLAIN: epilogues 0-2 on
+// plain x.  FUSED (the geometries the decode step uses): also the reducing epilogues, and
+// for M <= 32 the norm prologue and the residual epilogue.
+template <typename T, int MT, int NW, int KSL, bool FUSED>
+static bool launch_cfg(int epi, bool norm, dim3 grid, hipStream_t s, MI355_LT_PARAMS, const FusedArgs& fa) {
+  if (!norm) {
+    if (epi == EPI_STORE) { launch_one<T, MT, NW, KSL, EPI_STORE, false>(grid, s, MI355_LT_ARGS, fa); return true; }
+    if (epi == EPI_SILU_MUL) { launch_one<T, MT, NW, KSL, EPI_SILU_MUL, false>(grid, s, MI355_LT_ARGS, fa); return true; }
+    if (epi == EPI_PARTIAL) { launch_one<T, MT, NW, KSL, EPI_PARTIAL, false>(grid, s, MI355_LT_ARGS, fa); return true; }
   }
+  if constexpr (FUSED) {
+    if (!norm && epi == EPI_REDUCE_STORE) {
+      launch_one<T, MT, NW, KSL, EPI_REDUCE_STORE, false>(grid, s, MI355_LT_ARGS, fa);
+      return true;
+    }
+    if constexpr (MT <= 2) {
+      if (!norm && epi == EPI_REDUCE_RESID) {
+        launch_one<T, MT, NW, KSL, EPI_REDUCE_RESID, false>(grid, s, MI355_LT_ARGS, fa);
+        return true;
+      }
+      if (norm && epi == EPI_STORE) { launch_one<T, MT, NW, KSL, EPI_STORE, true>(grid, s, MI355_LT_ARGS, fa); return true; }
+      if (norm && epi == EPI_SILU_MUL) { launch_one<T, MT, NW, KSL, EPI_SILU_MUL, true>(grid, s, MI355_LT_ARGS, fa); return true; }
+      if (norm && epi == EPI_PARTIAL) { launch_one<T, MT, NW, KSL, EPI_PARTIAL, true>(grid, s, MI355_LT_ARGS, fa); return true; }
+    }
+  }
+  return false;
 }
 
-template <typename T, int MT>
-static void launch_fused(int nw, int epi, bool norm, dim3 grid, hipStream_t s, MI355_LT_PARAMS, const FusedArgs& fa) {
-  if (nw == 8) launch_fused_epi<T, MT, 8, 1024>(epi, norm, grid, s, MI355_LT_ARGS, fa);
-  else launch_fused_epi<T, MT, 4, 512>(epi, norm, grid, s, MI355_LT_ARGS, fa);
+// The instantiated geometries: (m-tiles, waves per workgroup, x slice width).
+template <typename T>
+static bool launch_geometry(int mt, int nw, int ksl, int epi, bool norm, dim3 grid, hipStream_t s, MI355_LT_PARAMS,
+                            const FusedArgs& fa) {
+#define MI355_LT_GEOM(MT_, NW_, KSL_, FUSED_)           \
+  if (mt == MT_ && nw == NW_ && ksl == KSL_)            \
+    return launch_cfg<T, MT_, NW_, KSL_, FUSED_>(epi, norm, grid, s, MI355_LT_ARGS, fa);
+  MI355_LT_GEOM(1, 8, 1024, true) MI355_LT_GEOM(1, 4, 512, true) MI355_LT_GEOM(1, 4, 1024, false) MI355_LT_GEOM(1, 8, 512, false)
+  MI355_LT_GEOM(2, 8, 1024, true) MI355_LT_GEOM(2, 4, 512, true) MI355_LT_GEOM(2, 4, 1024, false) MI355_LT_GEOM(2, 8, 512, false)
+  MI355_LT_GEOM(4, 8, 512, true) MI355_LT_GEOM(4, 4, 256, true)
+  MI355_LT_GEOM(8, 8, 256, true)
+#undef MI355_LT_GEOM
+  return false;
+}
+
+// Shared argument checks + launch of both entry points.
+static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, float* partial, const void* x,
+                                   int64_t x_stride, const void* w_tiled, const void* bias, int32_t M, int32_t N,
+                                   int32_t K, int32_t tiles_per_wg, int32_t k_groups, int32_t epilogue,
+                                   const FusedArgs& fa, int32_t dtype, void* stream) {
+  const bool norm = fa.norm_w != nullptr;
+  const bool reduce = epilogue == EPI_REDUCE_STORE || epilogue == EPI_REDUCE_RESID;
+  MI355_REQUIRE(x && w_tiled, MI355_ERR_INVALID, "%s: null pointer", name);
+  MI355_REQUIRE(M >= 0 && M <= 128, MI355_ERR_UNSUPPORTED, "%s: M %d outside [0, 128]", name, M);
+  MI355_REQUIRE(epilogue >= EPI_STORE && epilogue <= EPI_REDUCE_RESID, MI355_ERR_INVALID, "%s: unknown epilogue %d",
+                name, epilogue);
+  // tiles_per_wg: 4 or 8 tiles (= waves) per workgroup; +100 selects the narrow x slice.  The slice is
+  // 1024 (narrow: 512) wide up to 32 rows and halves with every doubling of the rows, so that the
+  // double-buffered x image keeps its LDS footprint.
+  const int nw = tiles_per_wg % 100;
+  MI355_REQUIRE((nw == 4 || nw == 8) && (tiles_per_wg == nw || tiles_per_wg == nw + 100), MI355_ERR_INVALID,
+                "%s: tiles_per_wg must be 4, 8, 104 or 108", name);
+  const int mt = M <= 16 ? 1 : M <= 32 ? 2 : M <= 64 ? 4 : 8;
+  const int ksl = (tiles_per_wg >= 100 ? 512 : 1024) / (mt <= 2 ? 1 : mt / 2);
+  MI355_REQUIRE(N > 0 && K > 0 && K % ksl == 0, MI355_ERR_UNSUPPORTED,
+                "%s: K %d must be a multiple of the x slice %d (M %d)", name, K, ksl, M);
+  const int phases = K / ksl;
+  MI355_REQUIRE(k_groups >= 1 && phases % k_groups == 0, MI355_ERR_INVALID, "%s: k_groups %d must divide K/%d = %d",
+                name, k_groups, ksl, phases);
+  const int ppg = phases / k_groups;
+  MI355_REQUIRE(ksl >= 512 || ppg % 2 == 0, MI355_ERR_UNSUPPORTED,
+                "%s: with %d-wide slices every workgroup needs an even number of them (K/%d/k_groups = %d)", name,
+                ksl, ksl, ppg);
+  MI355_REQUIRE(k_groups == 1 || epilogue == EPI_PARTIAL || reduce, MI355_ERR_INVALID,
+                "%s: k_groups > 1 needs a partial-sum or reducing epilogue", name);
+  MI355_REQUIRE(x_stride >= K && x_stride % 8 == 0 && aligned16(x) && aligned16(w_tiled), MI355_ERR_INVALID,
+                "%s: x/w_tiled must be 16-byte aligned, x_stride a multiple of 8", name);
+  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED,
+                "%s: dtype %d not supported (bf16/fp16 only)", name, dtype);
+  if (norm)
+    MI355_REQUIRE(fa.sumsq_in && fa.norm_parts >= 1 && aligned16(fa.norm_w) && fa.eps >= 0.f && !reduce && M <= 32,
+                  MI355_ERR_INVALID,
+                  "%s: norm prologue needs norm_sumsq, norm_parts >= 1, a 16-byte aligned weight, M <= 32 and a "
+                  "non-reducing epilogue", name);
+  if (epilogue == EPI_PARTIAL || reduce)
+    MI355_REQUIRE(partial && aligned16(partial), MI355_ERR_INVALID, "%s: partial buffer missing", name);
+  if (reduce) {
+    MI355_REQUIRE(fa.counters && N % 8 == 0, MI355_ERR_INVALID, "%s: reducing epilogues need counters and N %% 8 == 0",
+                  name);
+    MI355_REQUIRE(bias == nullptr || aligned16(bias), MI355_ERR_INVALID, "%s: bias must be 16-byte aligned", name);
+  }
+  if (epilogue == EPI_REDUCE_RESID)
+    MI355_REQUIRE(fa.resid && fa.sumsq_out && aligned16(fa.resid) && fa.resid_stride >= N && fa.resid_stride % 8 == 0 &&
+                      M <= 32,
+                  MI355_ERR_INVALID,
+                  "%s: residual (16-byte aligned, stride >= N, multiple of 8), sumsq_out and M <= 32 needed", name);
+  if (epilogue == EPI_STORE || epilogue == EPI_SILU_MUL || epilogue == EPI_REDUCE_STORE)
+    MI355_REQUIRE(y && y_stride >= (epilogue == EPI_SILU_MUL ? N / 2 : N) &&
+                      (epilogue != EPI_REDUCE_STORE || (aligned16(y) && y_stride % 8 == 0)),
+                  MI355_ERR_INVALID, "%s: y missing, misaligned or y_stride too small", name);
+  if (epilogue == EPI_SILU_MUL)
+    MI355_REQUIRE(N % 32 == 0 && bias == nullptr, MI355_ERR_UNSUPPORTED,
+                  "%s: SwiGLU epilogue needs N %% 32 == 0 and no bias", name);
+  if (M == 0) return MI355_OK;
+  const int tiles_total = (N + 15) / 16;
+  dim3 grid((tiles_total + nw - 1) / nw, k_groups);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  auto* yp = static_cast<uint16_t*>(y);
+  auto* xp = static_cast<const uint16_t*>(x);
+  auto* wp = static_cast<const uint16_t*>(w_tiled);
+  auto* bp = static_cast<const uint16_t*>(bias);
+  const bool ok = dtype == MI355_BF16
+                      ? launch_geometry<BF16>(mt, nw, ksl, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K,
+                                              x_stride, y_stride, tiles_total, ppg, fa)
+                      : launch_geometry<F16>(mt, nw, ksl, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K,
+                                             x_stride, y_stride, tiles_total, ppg, fa);
+  MI355_REQUIRE(ok, MI355_ERR_UNSUPPORTED,
+                "%s: no kernel for M %d with tiles_per_wg %d, epilogue %d%s (M <= 32: 4/8/104/108, fused forms 8/104; "
+                "M <= 64: 8/104; M <= 128: 8)", name, M, tiles_per_wg, epilogue, norm ? " + norm prologue" : "");
+  return check_launch(name);
 }
 
 }  // namespace mi355
@@ -445,52 +538,10 @@ extern "C" int32_t mi355_linear_tiled(void* y, int64_t y_stride, void* partial, 
                                       void* stream) {
   using namespace mi355;
   const char* name = "mi355_linear_tiled";
-  MI355_REQUIRE(x && w_tiled, MI355_ERR_INVALID, "%s: null pointer", name);
-  MI355_REQUIRE(M >= 0 && M <= 32, MI355_ERR_UNSUPPORTED, "%s: M %d outside [0, 32]", name, M);
-  MI355_REQUIRE(N > 0 && K > 0 && K % 512 == 0, MI355_ERR_UNSUPPORTED, "%s: K %d must be a multiple of 512", name, K);
   MI355_REQUIRE(epilogue == EPI_STORE || epilogue == EPI_SILU_MUL || epilogue == EPI_PARTIAL, MI355_ERR_INVALID,
                 "%s: unknown epilogue %d", name, epilogue);
-  // tiles_per_wg: 4 or 8 tiles (= waves) per workgroup; +100 selects 512-wide x slices (two
-  // workgroups per CU) instead of 1024-wide ones
-  const int nw = tiles_per_wg % 100, ksl = tiles_per_wg >= 100 ? 512 : 1024;
-  MI355_REQUIRE((nw == 4 || nw == 8) && (tiles_per_wg == nw || tiles_per_wg == nw + 100), MI355_ERR_INVALID,
-                "%s: tiles_per_wg must be 4, 8, 104 or 108", name);
-  MI355_REQUIRE(K % ksl == 0, MI355_ERR_UNSUPPORTED, "%s: K %d must be a multiple of the x slice %d", name, K, ksl);
-  const int phases = K / ksl;
-  MI355_REQUIRE(k_groups >= 1 && phases % k_groups == 0, MI355_ERR_INVALID,
-                "%s: k_groups %d must divide K/%d = %d", name, k_groups, ksl, phases);
-  MI355_REQUIRE(k_groups == 1 || epilogue == EPI_PARTIAL, MI355_ERR_INVALID,
-                "%s: k_groups > 1 needs the partial-sum epilogue", name);
-  if (epilogue == EPI_PARTIAL)
-    MI355_REQUIRE(partial && aligned16(partial), MI355_ERR_INVALID, "%s: partial buffer missing", name);
-  else
-    MI355_REQUIRE(y && y_stride >= (epilogue == EPI_SILU_MUL ? N / 2 : N), MI355_ERR_INVALID,
-                  "%s: y missing or y_stride too small", name);
-  if (epilogue == EPI_SILU_MUL)
-    MI355_REQUIRE(N % 32 == 0 && bias == nullptr, MI355_ERR_UNSUPPORTED,
-                  "%s: SwiGLU epilogue needs N %% 32 == 0 and no bias", name);
-  MI355_REQUIRE(x_stride >= K && x_stride % 8 == 0 && aligned16(x) && aligned16(w_tiled), MI355_ERR_INVALID,
-                "%s: x/w_tiled must be 16-byte aligned, x_stride a multiple of 8", name);
-  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED,
-                "%s: dtype %d not supported (bf16/fp16 only)", name, dtype);
-  if (M == 0) return MI355_OK;
-  const int tiles_total = (N + 15) / 16;
-  dim3 grid((tiles_total + nw - 1) / nw, k_groups);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  auto* yp = static_cast<uint16_t*>(y);
-  auto* pp = static_cast<float*>(partial);
-  auto* xp = static_cast<const uint16_t*>(x);
-  auto* wp = static_cast<const uint16_t*>(w_tiled);
-  auto* bp = static_cast<const uint16_t*>(bias);
-  const int ppg = phases / k_groups;
-  if (dtype == MI355_BF16) {
-    if (M <= 16) launch_geom<BF16, 1>(nw, ksl, epilogue, grid, s, yp, pp, xp, wp, bp, M, N, K, x_stride, y_stride, tiles_total, ppg);
-    else launch_geom<BF16, 2>(nw, ksl, epilogue, grid, s, yp, pp, xp, wp, bp, M, N, K, x_stride, y_stride, tiles_total, ppg);
-  } else {
-    if (M <= 16) launch_geom<F16, 1>(nw, ksl, epilogue, grid, s, yp, pp, xp, wp, bp, M, N, K, x_stride, y_stride, tiles_total, ppg);
-    else launch_geom<F16, 2>(nw, ksl, epilogue, grid, s, yp, pp, xp, wp, bp, M, N, K, x_stride, y_stride, tiles_total, ppg);
-  }
-  return check_launch(name);
+  return linear_tiled_launch(name, y, y_stride, static_cast<float*>(partial), x, x_stride, w_tiled, bias, M, N, K,
+                             tiles_per_wg, k_groups, epilogue, FusedArgs{}, dtype, stream);
 }
 
 extern "C" int32_t mi355_linear_tiled_fused(void* y, int64_t y_stride, float* partial, const void* x,
@@ -500,67 +551,8 @@ extern "C" int32_t mi355_linear_tiled_fused(void* y, int64_t y_stride, float* pa
                                             int32_t norm_parts, float eps, void* residual, int64_t residual_stride,
                                             float* sumsq_out, uint32_t* counters, int32_t dtype, void* stream) {
   using namespace mi355;
-  const char* name = "mi355_linear_tiled_fused";
-  const bool norm = norm_weight != nullptr;
-  const bool reduce = epilogue == EPI_REDUCE_STORE || epilogue == EPI_REDUCE_RESID;
-  if (!norm && !reduce)  // nothing fused: the plain entry point covers it
-    return mi355_linear_tiled(y, y_stride, partial, x, x_stride, w_tiled, bias, M, N, K, tiles_per_wg, k_groups,
-                              epilogue, dtype, stream);
-  MI355_REQUIRE(x && w_tiled, MI355_ERR_INVALID, "%s: null pointer", name);
-  MI355_REQUIRE(M >= 0 && M <= 32, MI355_ERR_UNSUPPORTED, "%s: M %d outside [0, 32]", name, M);
-  MI355_REQUIRE(epilogue >= EPI_STORE && epilogue <= EPI_REDUCE_RESID, MI355_ERR_INVALID, "%s: unknown epilogue %d",
-                name, epilogue);
-  MI355_REQUIRE(!(norm && reduce), MI355_ERR_UNSUPPORTED,
-                "%s: the norm prologue is built for epilogues 0-2, the reducing epilogues for plain x", name);
-  MI355_REQUIRE(tiles_per_wg == 8 || tiles_per_wg == 104, MI355_ERR_UNSUPPORTED,
-                "%s: fused forms exist for tiles_per_wg 8 (1024-wide slices) and 104 (512-wide)", name);
-  const int nw = tiles_per_wg % 100, ksl = tiles_per_wg >= 100 ? 512 : 1024;
-  MI355_REQUIRE(N > 0 && K > 0 && K % ksl == 0, MI355_ERR_UNSUPPORTED, "%s: K %d must be a multiple of %d", name, K, ksl);
-  const int phases = K / ksl;
-  MI355_REQUIRE(k_groups >= 1 && phases % k_groups == 0, MI355_ERR_INVALID, "%s: k_groups %d must divide K/%d = %d",
-                name, k_groups, ksl, phases);
-  MI355_REQUIRE(k_groups == 1 || epilogue == EPI_PARTIAL || reduce, MI355_ERR_INVALID,
-                "%s: k_groups > 1 needs a partial-sum or reducing epilogue", name);
-  MI355_REQUIRE(x_stride >= K && x_stride % 8 == 0 && aligned16(x) && aligned16(w_tiled), MI355_ERR_INVALID,
-                "%s: x/w_tiled must be 16-byte aligned, x_stride a multiple of 8", name);
-  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED,
-                "%s: dtype %d not supported (bf16/fp16 only)", name, dtype);
-  if (norm)
-    MI355_REQUIRE(norm_sumsq && norm_parts >= 1 && aligned16(norm_weight) && eps >= 0.f, MI355_ERR_INVALID,
-                  "%s: norm prologue needs norm_sumsq, norm_parts >= 1 and a 16-byte aligned weight", name);
-  if (epilogue == EPI_PARTIAL || reduce)
-    MI355_REQUIRE(partial && aligned16(partial), MI355_ERR_INVALID, "%s: partial buffer missing", name);
-  if (reduce) {
-    MI355_REQUIRE(counters && N % 8 == 0, MI355_ERR_INVALID, "%s: reducing epilogues need counters and N %% 8 == 0", name);
-    MI355_REQUIRE(bias == nullptr || aligned16(bias), MI355_ERR_INVALID, "%s: bias must be 16-byte aligned", name);
-  }
-  if (epilogue == EPI_REDUCE_RESID)
-    MI355_REQUIRE(residual && sumsq_out && aligned16(residual) && residual_stride >= N && residual_stride % 8 == 0,
-                  MI355_ERR_INVALID, "%s: residual (16-byte aligned, stride >= N, multiple of 8) and sumsq_out needed", name);
-  if (epilogue == EPI_STORE || epilogue == EPI_SILU_MUL || epilogue == EPI_REDUCE_STORE)
-    MI355_REQUIRE(y && y_stride >= (epilogue == EPI_SILU_MUL ? N / 2 : N) &&
-                      (epilogue != EPI_REDUCE_STORE || (aligned16(y) && y_stride % 8 == 0)),
-                  MI355_ERR_INVALID, "%s: y missing, misaligned or y_stride too small", name);
-  if (epilogue == EPI_SILU_MUL)
-    MI355_REQUIRE(N % 32 == 0 && bias == nullptr, MI355_ERR_UNSUPPORTED,
-                  "%s: SwiGLU epilogue needs N %% 32 == 0 and no bias", name);
-  if (M == 0) return MI355_OK;
-  const int tiles_total = (N + 15) / 16;
-  dim3 grid((tiles_total + nw - 1) / nw, k_groups);
-  FusedArgs fa{static_cast<const uint16_t*>(norm_weight), norm_sumsq, norm_parts, eps,
-               static_cast<uint16_t*>(residual), residual_stride, sumsq_out, counters};
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  auto* yp = static_cast<uint16_t*>(y);
-  auto* xp = static_cast<const uint16_t*>(x);
-  auto* wp = static_cast<const uint16_t*>(w_tiled);
-  auto* bp = static_cast<const uint16_t*>(bias);
-  const int ppg = phases / k_groups;
-  if (dtype == MI355_BF16) {
-    if (M <= 16) launch_fused<BF16, 1>(nw, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K, x_stride, y_stride, tiles_total, ppg, fa);
-    else launch_fused<BF16, 2>(nw, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K, x_stride, y_stride, tiles_total, ppg, fa);
-  } else {
-    if (M <= 16) launch_fused<F16, 1>(nw, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K, x_stride, y_stride, tiles_total, ppg, fa);
-    else launch_fused<F16, 2>(nw, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K, x_stride, y_stride, tiles_total, ppg, fa);
-  }
-  return check_launch(name);
+  const FusedArgs fa{static_cast<const uint16_t*>(norm_weight), norm_sumsq, norm_parts, eps,
+                     static_cast<uint16_t*>(residual), residual_stride, sumsq_out, counters};
+  return linear_tiled_launch("mi355_linear_tiled_fused", y, y_stride, partial, x, x_stride, w_tiled, bias, M, N, K,
+                             tiles_per_wg, k_groups, epilogue, fa, dtype, stream);
 }

@@ -279,32 +279,47 @@ def sample(logits: torch.Tensor, temperature: torch.Tensor, top_k: torch.Tensor,
 
 EPI_STORE, EPI_SILU_MUL, EPI_PARTIAL, EPI_REDUCE_STORE, EPI_REDUCE_RESID = 0, 1, 2, 3, 4
 SUMSQ_ROWS = 32                      # row pitch of the sum-of-squares tables
-LINEAR_TILED_MAX_M = 32
-LINEAR_TILED_K_MULTIPLE = 1024       # (512 with the 104/108 geometries)
+LINEAR_TILED_MAX_M = 128
 
 
-def plan_linear_tiled(N: int, K: int, split_k: bool):
-    """(tiles_per_wg, k_groups) for linear_tiled on an [N, K] weight, or None when the
-    kernel does not cover the shape.  One workgroup per CU (>= ~192 workgroups) is what
-    saturates the weight stream: wide layers take 8 tiles per workgroup and 1024-wide x
-    slices, unsplit; narrower ones take 4 tiles and 512-wide slices (two workgroups per
-    CU) and, when the caller can consume or reduce fp32 partial sums, split K over
-    workgroups until there are enough of them."""
-    if K % 512:
+def tiled_slice_width(M: int, tiles_per_wg: int) -> int:
+    """K slice of x a workgroup of linear_tiled stages at a time."""
+    mt = 1 if M <= 16 else 2 if M <= 32 else 4 if M <= 64 else 8
+    return (512 if tiles_per_wg >= 100 else 1024) // (1 if mt <= 2 else mt // 2)
+
+
+def plan_linear_tiled(N: int, K: int, split_k: bool, M: int = 32):
+    """(tiles_per_wg, k_groups) for linear_tiled on an [N, K] weight and M rows, or None when
+    the kernel does not cover the shape.  One workgroup per CU (>= ~192 workgroups) is what
+    saturates the weight stream: wide layers take 8 tiles per workgroup, unsplit; narrower
+    ones take 4 tiles and the narrow x slice (two workgroups per CU; 8 tiles beyond 64 rows)
+    and, when the caller can consume or reduce fp32 partial sums, split K over workgroups
+    until there are enough of them."""
+    if M > LINEAR_TILED_MAX_M:
         return None
     tiles_total = (N + 15) // 16
-    if tiles_total >= 8 * 160 and K % 1024 == 0:
-        return 8, 1
-    groups = 1
-    if split_k:
-        wgs = -(-tiles_total // 4)
-        phases = K // 512
-        for g in (1, 2, 4, 7, 8):
-            if phases % g == 0:
-                groups = g
-                if wgs * g >= 192:
-                    break
-    return 104, groups
+    if M > 64:
+        candidates = [8]
+    elif tiles_total >= 8 * 160:
+        candidates = [8, 104]
+    else:
+        candidates = [104]
+    for tiles in candidates:
+        ksl = tiled_slice_width(M, tiles)
+        if K % ksl:
+            continue
+        phases = K // ksl
+        wgs = -(-tiles_total // (tiles % 100))
+        best = None
+        for g in ((1, 2, 4, 7, 8, 14, 16) if split_k and wgs < 160 else (1,)):
+            if phases % g or (ksl < 512 and (phases // g) % 2):
+                continue
+            best = g
+            if wgs * g >= 192:
+                break
+        if best is not None:
+            return tiles, best
+    return None
 
 
 def tile_weights(weight: torch.Tensor, interleave_halves: bool = False) -> torch.Tensor:
@@ -324,7 +339,7 @@ def tile_weights(weight: torch.Tensor, interleave_halves: bool = False) -> torch
 def linear_tiled(x: torch.Tensor, w_tiled: torch.Tensor, N: int, bias: torch.Tensor | None = None,
                  out: torch.Tensor | None = None, partial: torch.Tensor | None = None, tiles_per_wg: int = 0,
                  k_groups: int = 1, epilogue: int = EPI_STORE):
-    """y = x @ W.T on fragment-tiled weights (M <= 32, K % 1024 == 0).  Returns `out`
+    """y = x @ W.T on fragment-tiled weights (M <= 128).  Returns `out`
     ([M, N], or [M, N/2] with the SwiGLU epilogue) or `partial` ([k_groups, M, N] fp32)."""
     dt = _dt16(x, "x")
     _dev(w_tiled, "w_tiled")
@@ -333,7 +348,7 @@ def linear_tiled(x: torch.Tensor, w_tiled: torch.Tensor, N: int, bias: torch.Ten
         raise ValueError("w_tiled does not match (N, K) / dtype")
     tiles_total = (N + 15) // 16
     if tiles_per_wg == 0:                         # 8 tiles (waves) per workgroup once that still fills the chip
-        tiles_per_wg = 8 if -(-tiles_total // 8) * k_groups >= 160 else 4
+        tiles_per_wg = 8 if M > 64 or -(-tiles_total // 8) * k_groups >= 160 else (4 if M <= 32 else 104)
     y_ptr = p_ptr = 0
     y_stride = 0
     if epilogue == EPI_PARTIAL:
