@@ -120,12 +120,15 @@ def time_kernels(engine, batch, ctx_len):
     x, qkv, attn, o, gu, act, dn, resid = r.x[:b], r.qkv[:b], r.attn[:b], r.o[:b], r.gu[:b], r.act[:b], r.dn[:b], r.resid[:b]
     W = r.w.layers
     gemm = lambda m, n, k, out_es=es: n * k * es + m * k * es + m * n * out_es   # noqa: E731
-    tiled = r.tiled is not None and b <= r.tiled_max_m
+    tiled = r._use_tiled(b)
     if tiled:
         T, P = r.tiled, ops.EPI_PARTIAL
-        (tq, gq), (to, go), (tg, _), (td, gd) = (r.tiled_plans[k] for k in ("qkv", "o", "gu", "down"))
+        plans = r._tiled_plan(b)
+        (tq, gq), (tg, _), (td, gd) = (plans[k] for k in ("qkv", "gu", "down"))
+        to, go = plans.get("o", (0, 1))
         out["impl"] = ("hand-written weight-streaming GEMMs on fragment-tiled weights (linear_tiled_kernel); "
-                       f"geometry qkv {tq}/{gq}, o {to}/{go}, gate_up {tg}/1 + SwiGLU epilogue, down {td}/{gd}")
+                       f"geometry qkv {tq}/{gq}, o {to}/{go}, gate_up {tg}/1 + SwiGLU epilogue, down {td}/{gd}"
+                       + ("" if "o" in plans else "; o projection: hipBLASLt (16-bit output for the all-reduce)"))
         out["gemm_gate_up"] = timed(lambda i: ops.linear_tiled(x, T[i]["gu"], 2 * r.F, out=act, tiles_per_wg=tg,
                                                                epilogue=ops.EPI_SILU_MUL),
                                     2 * r.F * r.H * es + b * r.H * es + b * r.F * es)
@@ -133,8 +136,11 @@ def time_kernels(engine, batch, ctx_len):
                                                             k_groups=gd, epilogue=P), gemm(b, r.H, r.F, 4 * gd))
         out["gemm_qkv"] = timed(lambda i: ops.linear_tiled(x, T[i]["qkv"], r.qw, partial=r.part_qkv, tiles_per_wg=tq,
                                                            k_groups=gq, epilogue=P), gemm(b, r.qw, r.H, 4 * gq))
-        out["gemm_o"] = timed(lambda i: ops.linear_tiled(attn, T[i]["o"], r.H, partial=r.part_o, tiles_per_wg=to,
-                                                         k_groups=go, epilogue=P), gemm(b, r.H, r.nh * r.d, 4 * go))
+        if "o" in plans:
+            out["gemm_o"] = timed(lambda i: ops.linear_tiled(attn, T[i]["o"], r.H, partial=r.part_o, tiles_per_wg=to,
+                                                             k_groups=go, epilogue=P), gemm(b, r.H, r.nh * r.d, 4 * go))
+        else:
+            out["gemm_o"] = timed(lambda i: torch.mm(attn, W[i].o_w.t(), out=o), gemm(b, r.H, r.nh * r.d))
     else:
         out["impl"] = "library GEMMs (hipBLASLt through torch.mm) on row-major weights"
         out["gemm_gate_up"] = timed(lambda i: torch.mm(x, W[i].gate_up_w.t(), out=gu), gemm(b, 2 * r.F, r.H))
@@ -160,8 +166,8 @@ def time_kernels(engine, batch, ctx_len):
                                         r.nkv, r.d, partial=r.part_qkv, num_slabs=gq, bias=W[i].qkv_b),
             b * r.qw * (4 * gq + es) + b * 2 * r.nkv * r.d * es)
         out["fused_add_rms_norm"] = timed(
-            lambda i: ops.fused_add_rms_norm_partial(r.part_o, go, resid, W[i].post_norm, r.eps, x),
-            b * r.H * (4 * go + 3 * es))
+            lambda i: ops.fused_add_rms_norm_partial(r.part_dn, gd, resid, W[i].post_norm, r.eps, x),
+            b * r.H * (4 * gd + 3 * es))
     else:
         out["rope_kv_write"] = timed(
             lambda i: ops.rope_kv_write(qkv, r.positions[:b], r.cos_sin, r.slots[:b], r.k_cache[i], r.v_cache[i], r.nh,

@@ -268,3 +268,59 @@ def test_tiled_and_library_gemm_paths_both_match_oracle(name, monkeypatch):
     assert eng_l.runner.tiled is None
     got_l = _oracle_checked(eng_l, cfg, w, prompts, 16, f"{name} library GEMMs")
     assert (got_t[:, 0] == got_l[:, 0]).all()          # first token comes from the shared prefill path
+
+
+@pytest.mark.parametrize("nseq", [40, 72])
+def test_batches_of_33_to_128_rows_match_oracle(nseq):
+    """Decode batches beyond 32 rows take the 4- and 8-m-tile GEMM kernels."""
+    name = "llama_d128"
+    rng = np.random.Generator(np.random.PCG64(nseq))
+    lengths = rng.integers(3, 30, nseq).tolist()
+    prompts = make_prompts(name, nseq, lengths, seed=7)
+    eng, cfg, w = build(name, "bfloat16", max_num_seqs=nseq)
+    r = eng.runner
+    assert r._use_tiled(r.bucket_for(nseq)), "tiled decode path not active at this batch size"
+    ref_tokens, ref_logits = M.greedy_generate(
+        M.RefModel(M.RefConfig(**cfg), w, "bfloat16", num_blocks=nseq * 8), prompts, 6)
+    scale = np.abs(ref_logits[0]).max()
+    got = engine_generate(eng, prompts, 6)
+    exact = compare_tokens(got, ref_tokens, ref_logits, LOGIT_TOL["bfloat16"] * scale * 2)
+    print(f"{nseq} sequences: {exact}/{ref_tokens.size} tokens identical to the oracle before the first near-tie")
+    assert exact >= 0.6 * ref_tokens.size
+
+
+@pytest.mark.parametrize("batch", [4, 48])
+def test_tensor_parallel_rank_step_tiled_vs_library(batch, monkeypatch):
+    """One tensor-parallel rank's decode step (its shard of the heads; the all-reduce
+    replaced by a no-op, so the step computes that rank's share only) on the tiled
+    weights against the same step on library GEMMs: the two implementations of the
+    rank's arithmetic must agree to the logit bound."""
+    from mi355_decode import weights as W
+    from mi355_decode.config import ModelConfig
+    from mi355_decode.model_runner import ModelRunner
+    name, dtype = "llama_d128", "bfloat16"
+    arch, cfg, w = make_weights(name)
+    mc = ModelConfig.from_dict({**cfg, "architectures": [arch]})
+    sd = {k: torch.from_numpy(R.round_to(v, dtype)) for k, v in w.items()}
+    logits = {}
+    for tiled in (True, False):
+        ws = W.from_state_dict(mc, sd, torch.bfloat16, "cuda", tp_rank=1, tp_size=2)
+        r = ModelRunner(mc, ws, torch.bfloat16, "cuda", num_blocks=batch * 4, max_num_seqs=batch, max_model_len=64,
+                        tp_rank=1, tp_size=2, tp_group=None, tiled_linears=tiled)
+        monkeypatch.setattr(r, "_allreduce", lambda t: None)
+        assert (r.tiled is not None) == tiled
+        n64, n32 = r.host_inputs()
+        B = r.max_num_seqs
+        rng = np.random.Generator(np.random.PCG64(3))
+        n64[:B] = rng.integers(0, cfg["vocab_size"], B)
+        bt = n32[B:].reshape(B, r.max_blocks)
+        for step in range(3):                                   # three tokens per sequence, pages 4b..4b+3
+            for b in range(B):
+                n64[B + b], n64[2 * B + b], n32[b] = step, (4 * b) * 16 + step, step + 1
+                bt[b, :4] = np.arange(4 * b, 4 * b + 4)
+            r.run_decode(B)
+        logits[tiled] = r.logits[:B].float().cpu().numpy()
+    scale = np.abs(logits[False]).max()
+    err = np.abs(logits[True] - logits[False])
+    assert np.isfinite(logits[True]).all()
+    assert err.max() <= LOGIT_TOL[dtype] * scale and err.mean() <= LOGIT_MEAN_TOL[dtype] * scale

@@ -86,12 +86,11 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
                         args.model)
         weights = W.synthetic(cfg, dtype, device, seed=args.seed, **kw)
     tp = kw["tp_size"]
-    # the runner keeps a second, fragment-tiled copy of the per-layer matrices (TP=1 only)
-    tiled_bytes = 0
-    if tp == 1:
-        tiled_bytes = sum(t.numel() * t.element_size() for lw in weights.layers
-                          for t in (lw.qkv_w, lw.o_w, lw.gate_up_w, lw.down_w))
-        tiled_bytes += weights.lm_head.numel() * weights.lm_head.element_size()
+    # the runner keeps a second, fragment-tiled copy of the decode-time matrices (the o
+    # projection only without tensor parallelism)
+    tiled_bytes = sum(t.numel() * t.element_size() for lw in weights.layers
+                      for t in (lw.qkv_w, lw.gate_up_w, lw.down_w) + ((lw.o_w,) if tp == 1 else ()))
+    tiled_bytes += weights.lm_head.numel() * weights.lm_head.element_size()
     num_blocks = plan_num_blocks(args, cfg, tp, len(weights.layers), max_model_len,
                                  torch.empty(0, dtype=dtype).element_size(), device, extra_reserve=tiled_bytes)
     runner = ModelRunner(cfg, weights, dtype, device, num_blocks, args.max_num_seqs, max_model_len,

@@ -126,42 +126,65 @@ class ModelRunner:
 
     # ------------------------------------------------------------------ #
     def _init_tiled(self, want: Optional[bool]) -> None:
-        """Fragment-tiled copies of the per-layer weights for decode batches <= 32.
-        Only without tensor parallelism: the K-split o/down projections leave fp32
-        partial sums that the next norm kernel consumes, which has no place for the
-        all-reduce a sharded o/down projection needs."""
+        """Fragment-tiled copies of the weights for decode batches of up to 128 rows.
+        Under tensor parallelism the o projection stays a library GEMM: its output has to
+        be a 16-bit tensor for the all-reduce, and the K-split kernel's strength is handing
+        fp32 partial sums to the next kernel."""
         import os
         if want is None:
             want = os.environ.get("MI355_TILED_LINEARS", "1") != "0"
         self.tiled = None
-        if not want or self.tp_size != 1 or self.dtype not in (torch.bfloat16, torch.float16):
+        if not want or self.dtype not in (torch.bfloat16, torch.float16) or (2 * self.F) % 32:
             return
-        shapes = {"qkv": (self.qw, self.H, True), "o": (self.H, self.nh * self.d, True),
-                  "gu": (2 * self.F, self.H, False), "down": (self.H, self.F, True)}
-        plans = {k: ops.plan_linear_tiled(n, kk, split) for k, (n, kk, split) in shapes.items()}
-        if any(p is None for p in plans.values()) or (2 * self.F) % 32:
+        self.tiled_shapes = {"qkv": (self.qw, self.H, True), "gu": (2 * self.F, self.H, False),
+                             "down": (self.H, self.F, True), "lm_head": (self.V, self.H, False)}
+        if self.tp_size == 1:
+            self.tiled_shapes["o"] = (self.H, self.nh * self.d, True)
+        self._plan_cache = {}
+        self.tiled_max_m = 0
+        for m in (16, 32, 64, 128):                   # largest row count every layer has a kernel for
+            if self._tiled_plan(m) is None:
+                break
+            self.tiled_max_m = m
+        self.tiled_max_m = min(self.tiled_max_m, self.max_num_seqs)
+        if self.tiled_max_m == 0:
             return
-        self.tiled_plans = plans
-        self.tiled_max_m = min(ops.LINEAR_TILED_MAX_M, self.max_num_seqs)
         self.tiled = []
         for lw in self.w.layers:
-            self.tiled.append({"qkv": ops.tile_weights(lw.qkv_w), "o": ops.tile_weights(lw.o_w),
-                               "gu": ops.tile_weights(lw.gate_up_w, interleave_halves=True),
-                               "down": ops.tile_weights(lw.down_w)})
-        self.lm_head_plan = ops.plan_linear_tiled(self.V, self.H, False)
-        self.lm_head_tiled = ops.tile_weights(self.w.lm_head) if self.lm_head_plan is not None else None
-        m = self.tiled_max_m
+            tw = {"qkv": ops.tile_weights(lw.qkv_w), "gu": ops.tile_weights(lw.gate_up_w, interleave_halves=True),
+                  "down": ops.tile_weights(lw.down_w)}
+            if self.tp_size == 1:
+                tw["o"] = ops.tile_weights(lw.o_w)
+            self.tiled.append(tw)
+        self.lm_head_tiled = ops.tile_weights(self.w.lm_head)
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.part_qkv = torch.empty(plans["qkv"][1] * m * self.qw, **f32)
-        self.part_o = torch.empty(plans["o"][1] * m * self.H, **f32)
-        self.part_dn = torch.empty(plans["down"][1] * m * self.H, **f32)
+        size = {k: 0 for k in ("qkv", "o", "down")}
+        for m in (16, 32, 64, 128):
+            m = min(m, self.tiled_max_m)
+            for k in size:
+                if k in self.tiled_shapes:
+                    size[k] = max(size[k], self._tiled_plan(m)[k][1] * m * self.tiled_shapes[k][0])
+        self.part_qkv = torch.empty(size["qkv"], **f32)
+        self.part_o = torch.empty(max(size["o"], 4), **f32)
+        self.part_dn = torch.empty(size["down"], **f32)
+
+    def _tiled_plan(self, m: int):
+        """{layer: (tiles_per_wg, k_groups)} for m rows, or None if some layer has no kernel."""
+        if m not in self._plan_cache:
+            plans = {k: ops.plan_linear_tiled(n, kk, split, m) for k, (n, kk, split) in self.tiled_shapes.items()}
+            self._plan_cache[m] = None if any(p is None for p in plans.values()) else plans
+        return self._plan_cache[m]
+
+    def _use_tiled(self, b: int) -> bool:
+        return self.tiled is not None and b <= self.tiled_max_m and self._tiled_plan(b) is not None
 
     def _decode_layers_tiled(self, b: int, pos, slots, bt, ctx, splits) -> None:
-        """All decoder layers + the final norm for b <= 32 decode tokens; leaves the
-        normed hidden state in self.x[:b]."""
-        resid, x, qkv, attn, act = self.resid[:b], self.x[:b], self.qkv[:b], self.attn[:b], self.act[:b]
+        """All decoder layers + the final norm for b <= 128 decode tokens on the tiled
+        weights; leaves the normed hidden state in self.x[:b]."""
+        resid, x, qkv, attn, act, o = self.resid[:b], self.x[:b], self.qkv[:b], self.attn[:b], self.act[:b], self.o[:b]
         P = ops.EPI_PARTIAL
-        (tq, gq), (to, go), (tg, _), (td, gd) = (self.tiled_plans[k] for k in ("qkv", "o", "gu", "down"))
+        plans = self._tiled_plan(b)
+        (tq, gq), (tg, _), (td, gd) = (plans[k] for k in ("qkv", "gu", "down"))
         for i, (lw, tw) in enumerate(zip(self.w.layers, self.tiled)):
             if i == 0:
                 ops.rms_norm(resid, lw.input_norm, self.eps, out=x)
@@ -173,16 +196,23 @@ class ModelRunner:
             ops.paged_attn_decode(qkv[:, : self.nh * self.d], self.k_cache[i], self.v_cache[i], bt, ctx,
                                   self.nh, self.nkv, self.d, self.scale, num_splits=splits,
                                   workspace=self.attn_ws, out=attn)
-            ops.linear_tiled(attn, tw["o"], self.H, partial=self.part_o, tiles_per_wg=to, k_groups=go, epilogue=P)
-            ops.fused_add_rms_norm_partial(self.part_o, go, resid, lw.post_norm, self.eps, x)
+            if self.tp_size == 1:
+                to, go = plans["o"]
+                ops.linear_tiled(attn, tw["o"], self.H, partial=self.part_o, tiles_per_wg=to, k_groups=go, epilogue=P)
+                ops.fused_add_rms_norm_partial(self.part_o, go, resid, lw.post_norm, self.eps, x)
+            else:
+                torch.mm(attn, lw.o_w.t(), out=o)
+                self._allreduce(o)
+                ops.fused_add_rms_norm(o, resid, lw.post_norm, self.eps, out=x)
             ops.linear_tiled(x, tw["gu"], 2 * self.F, out=act, tiles_per_wg=tg, epilogue=ops.EPI_SILU_MUL)
             ops.linear_tiled(act, tw["down"], self.H, partial=self.part_dn, tiles_per_wg=td, k_groups=gd, epilogue=P)
         ops.fused_add_rms_norm_partial(self.part_dn, gd, resid, self.w.final_norm, self.eps, x)
 
     def lm_head_logits(self, x: torch.Tensor, out: torch.Tensor) -> None:
         """Decode-step logits of the rows in x."""
-        if self.tiled is not None and self.lm_head_tiled is not None and x.shape[0] <= self.tiled_max_m:
-            ops.linear_tiled(x, self.lm_head_tiled, self.V, out=out, tiles_per_wg=self.lm_head_plan[0])
+        if self._use_tiled(x.shape[0]):
+            ops.linear_tiled(x, self.lm_head_tiled, self.V, out=out,
+                             tiles_per_wg=self._tiled_plan(x.shape[0])["lm_head"][0])
         else:
             torch.mm(x, self.w.lm_head.t(), out=out)
 
@@ -232,7 +262,7 @@ class ModelRunner:
         o, gu, act, dn = self.o[:b], self.gu[:b], self.act[:b], self.dn[:b]
         splits = self._splits_for(b)
         torch.index_select(self.w.embed, 0, ids, out=resid)
-        if self.tiled is not None and b <= self.tiled_max_m:
+        if self._use_tiled(b):
             self._decode_layers_tiled(b, pos, slots, bt, ctx, splits)
             self.lm_head_logits(x, self.logits[:b])
             ops.argmax(self.logits[:b], out=self.next_ids[:b])
