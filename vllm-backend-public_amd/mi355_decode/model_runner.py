@@ -303,7 +303,10 @@ class ModelRunner:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # with a process group alive, its watchdog thread may touch the HIP runtime while this
+        # thread captures: only calls made by the capturing thread may end the capture
+        mode = "thread_local" if self.tp_size > 1 else "global"
+        with torch.cuda.graph(g, capture_error_mode=mode):
             self._decode_body(bucket)
         self.in64.copy_(saved64)
         self.in32.copy_(saved32)
