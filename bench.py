@@ -154,27 +154,27 @@ def time_kernels(engine, batch, ctx_len):
     splits = r._splits_for(b)
     ctx_tokens = int(r.ctx[:b].sum().item())              # the device buffers still hold the last step's inputs
     kv_bytes = ctx_tokens * 2 * r.nkv * r.d * es + 2 * b * r.nh * r.d * es
-    out["paged_attn_decode"] = timed(
-        lambda i: ops.paged_attn_decode(qkv[:, : r.nh * r.d], r.k_cache[i], r.v_cache[i], r.block_tables[:b], r.ctx[:b],
-                                        r.nh, r.nkv, r.d, r.scale, num_splits=splits, workspace=r.attn_ws, out=attn),
-        kv_bytes)
-    out["paged_attn_decode"]["splits"] = splits
     rope_bytes = b * ((r.nh + r.nkv) * r.d * 2 + r.nkv * r.d + 2 * r.nkv * r.d) * es
     if tiled:
-        out["rope_kv_write"] = timed(
-            lambda i: ops.rope_kv_write(qkv, r.positions[:b], r.cos_sin, r.slots[:b], r.k_cache[i], r.v_cache[i], r.nh,
-                                        r.nkv, r.d, partial=r.part_qkv, num_slabs=gq, bias=W[i].qkv_b),
-            b * r.qw * (4 * gq + es) + b * 2 * r.nkv * r.d * es)
+        out["paged_attn_decode_fused"] = timed(
+            lambda i: ops.paged_attn_decode_fused(None, r.cos_sin, r.slots[:b], r.k_cache[i], r.v_cache[i],
+                                                  r.block_tables[:b], r.ctx[:b], r.nh, r.nkv, r.d, r.scale,
+                                                  num_splits=splits, workspace=r.attn_ws, out=attn, partial=r.part_qkv,
+                                                  num_slabs=gq, bias=W[i].qkv_b),
+            kv_bytes + b * r.qw * 4 * gq + b * 2 * r.nkv * r.d * es)
         out["fused_add_rms_norm"] = timed(
             lambda i: ops.fused_add_rms_norm_partial(r.part_dn, gd, resid, W[i].post_norm, r.eps, x),
             b * r.H * (4 * gd + 3 * es))
     else:
-        out["rope_kv_write"] = timed(
-            lambda i: ops.rope_kv_write(qkv, r.positions[:b], r.cos_sin, r.slots[:b], r.k_cache[i], r.v_cache[i], r.nh,
-                                        r.nkv, r.d), rope_bytes)
+        out["paged_attn_decode_fused"] = timed(
+            lambda i: ops.paged_attn_decode_fused(qkv, r.cos_sin, r.slots[:b], r.k_cache[i], r.v_cache[i],
+                                                  r.block_tables[:b], r.ctx[:b], r.nh, r.nkv, r.d, r.scale,
+                                                  num_splits=splits, workspace=r.attn_ws, out=attn),
+            kv_bytes + rope_bytes)
         out["fused_add_rms_norm"] = timed(lambda i: ops.fused_add_rms_norm(o, resid, W[i].post_norm, r.eps, out=x),
                                           5 * b * r.H * es)
         out["silu_and_mul"] = timed(lambda i: ops.silu_and_mul(gu, out=act), 3 * b * r.F * es)
+    out["paged_attn_decode_fused"]["splits"] = splits
     out["argmax"] = timed(lambda i: ops.argmax(r.logits[:b], out=r.next_ids[:b]), b * r.V * es)
     return out
 

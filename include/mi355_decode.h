@@ -141,6 +141,35 @@ int32_t mi355_paged_attn_decode(void* out, const void* q, int64_t q_stride,
                                 void* stream);
 
 /*
+ * Decode attention with the rotary embedding and the KV store of the new token
+ * fused in: the projection of the step (packed q|k|v rows) is rotated and stored
+ * exactly as mi355_rope_kv_write would, then attended to exactly as
+ * mi355_paged_attn_decode would -- in one launch, and the rotated query never
+ * leaves the registers.  The projection comes either as 16-bit rows (qkv,
+ * qkv_stride; partial == NULL) or as the fp32 partial-sum slabs of a K-split
+ * GEMM (partial fp32 [num_slabs][num_seqs][width] + bias, as in
+ * mi355_rope_kv_write_partial; qkv may then be NULL).  The new token of
+ * sequence b sits at position context_lens[b] - 1 (that is its rotary position),
+ * and its slot must be the page slot of that token in the block table, as in
+ * every decode step; slot < 0: nothing stored.  Replaces the engine's
+ * rotary_embedding + reshape_and_cache + paged_attention_v1/v2 at decode.
+ */
+int32_t mi355_paged_attn_decode_fused(void* out, const void* qkv, int64_t qkv_stride,
+                                      const float* partial, int32_t num_slabs,
+                                      int64_t slab_stride, const void* bias,
+                                      const void* cos_sin, int32_t max_position,
+                                      const int64_t* slot_mapping, void* k_cache,
+                                      void* v_cache, int32_t num_blocks,
+                                      const int32_t* block_tables,
+                                      int32_t max_blocks_per_seq,
+                                      const int32_t* context_lens, int32_t num_seqs,
+                                      int32_t num_heads, int32_t num_kv_heads,
+                                      int32_t head_dim, float scale,
+                                      int32_t num_splits, void* workspace,
+                                      int64_t workspace_bytes, int32_t dtype,
+                                      void* stream);
+
+/*
  * Prefill (and chunked-prefill) attention: causal attention of packed
  * variable-length query chunks over keys/values already stored in the paged
  * cache.  Sequence i owns query rows [cu_seqlens[i], cu_seqlens[i+1]) sitting at

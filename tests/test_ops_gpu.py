@@ -729,3 +729,59 @@ def test_linear_tiled_rejects_unbuilt_geometries(ops):
                          64, tiles_per_wg=8)
     with pytest.raises(Mi355Error, match="outside"):
         ops.linear_tiled(torch.zeros(129, 1024, dtype=torch.bfloat16, device="cuda"), wt, 64)
+
+
+# --------------------------------------------------------------------------- #
+# decode attention with the rotary embedding + KV store fused in
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("nh,kvh,d", [(4, 2, 64), (32, 8, 128), (28, 4, 128), (7, 1, 64), (8, 1, 128)])
+@pytest.mark.parametrize("splits,slabs", [(1, 0), (1, 2), (3, 4), (2, 0)])
+def test_paged_attn_decode_fused(ops, dtype, nh, kvh, d, splits, slabs):
+    """One launch == rope_kv_write followed by paged_attn_decode: the attention output, the
+    K pages and the V pages are bit-identical, from 16-bit rows (slabs == 0) and from fp32
+    partial-sum slabs + bias; and the output matches the oracle."""
+    rng = rng_for("dec-fused", dtype, nh, kvh, d, splits, slabs)
+    ctxs = [1, 16, 17, 33, 128, 129, 200, 255, 513, 0, 64]
+    n = len(ctxs)
+    kc, vc, bt = build_paged(rng, ctxs, kvh, d, dtype, poison=False)
+    width = (nh + 2 * kvh) * d
+    max_pos = 1024
+    table = R.rope_cos_sin_table(max_pos, d, 5e5, dtype)
+    pos = np.array([max(c - 1, 0) for c in ctxs], np.int64)
+    slot = np.array([bt[i, p // 16] * 16 + p % 16 if c else -1 for i, (c, p) in enumerate(zip(ctxs, pos))], np.int64)
+    if slabs:
+        part = (rng.standard_normal((slabs, n, width)) * 0.6).astype(np.float32)
+        bias = grid(rng, (width,), dtype)
+        qkv = _slab_sum(part, bias, dtype)
+    else:
+        qkv = grid(rng, (n, width), dtype)
+    dv = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    ctx_d, bt_d, pos_d, slot_d, tab_d = dv(np.array(ctxs, np.int32)), dv(bt), dv(pos), dv(slot), dev(table, dtype)
+    scale = d ** -0.5
+
+    # two kernels
+    kc1, vc1, q1 = dev(kc, dtype), dev(vc, dtype), dev(qkv, dtype)
+    ops.rope_kv_write(q1, pos_d, tab_d, slot_d, kc1, vc1, nh, kvh, d)
+    out1 = ops.paged_attn_decode(q1[:, : nh * d], kc1, vc1, bt_d, ctx_d, nh, kvh, d, scale, num_splits=splits)
+    # one kernel
+    kc2, vc2 = dev(kc, dtype), dev(vc, dtype)
+    if slabs:
+        out2 = ops.paged_attn_decode_fused(None, tab_d, slot_d, kc2, vc2, bt_d, ctx_d, nh, kvh, d, scale,
+                                           num_splits=splits, partial=dv(part), num_slabs=slabs, bias=dev(bias, dtype))
+    else:
+        q2 = dev(qkv, dtype)
+        out2 = ops.paged_attn_decode_fused(q2, tab_d, slot_d, kc2, vc2, bt_d, ctx_d, nh, kvh, d, scale,
+                                           num_splits=splits)
+        np.testing.assert_array_equal(host(q2), qkv)             # the packed rows are left as they were
+    np.testing.assert_array_equal(host(kc2), host(kc1))
+    np.testing.assert_array_equal(host(vc2), host(vc1))
+    np.testing.assert_array_equal(host(out2), host(out1))
+
+    # and against the oracle
+    kc_ref, vc_ref = kc.copy(), vc.copy()
+    rot = R.rope_kv_write(qkv, pos, table, slot, kc_ref, vc_ref, nh, kvh, d, dtype)
+    ref = R.paged_attn_decode(rot[:, : nh * d].reshape(n, nh, d), kc_ref, vc_ref, bt, np.array(ctxs, np.int32), scale, dtype)
+    attn_close(host(out2).reshape(n, nh, d), ref, dtype)
+    np.testing.assert_array_equal(host(kc2), kc_ref)
+    np.testing.assert_array_equal(host(vc2), vc_ref)

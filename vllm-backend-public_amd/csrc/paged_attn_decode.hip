@@ -25,6 +25,17 @@
 //        B = the lane's own 8 probabilities, packed to 16 bits
 // HBM-bound: 2 * ctx * head_dim * 2 bytes per (sequence, kv head); MFMA use is
 // a few percent.
+//
+// Fused form (FUSE != 0): the rotary embedding and the KV store of the new token
+// happen here instead of in a kernel of their own.  Every wave forms the rotated
+// query fragments directly in the registers of the B operand (a lane's elements
+// [32ks + 8h, +8) and their rotation partners [.. + head_dim/2] are both its own,
+// so the rotation is lane-local); the workgroup whose token range holds the new
+// token rotates k, stores k and v to their pages, and the whole workgroup then
+// reads the pages as usual (release fence at workgroup scope + barrier between the
+// store and the loads; no other workgroup reads that slot in this launch).  The
+// projection comes either as packed 16-bit rows (FUSE == 1) or as the fp32
+// partial-sum slabs of a K-split GEMM (FUSE == 2: slab sum + bias, rounded, first).
 #include "common.h"
 
 #include <math.h>
@@ -35,13 +46,118 @@ constexpr int kDecodeThreads = 256;
 constexpr int kDecodeWaves = kDecodeThreads / 64;
 constexpr int kStep = 32;  // tokens per wave step (two 16-token pages)
 
-template <typename T, int D>
+struct RopeArgs {             // FUSE != 0
+  const float* partial;       // FUSE == 2: [num_slabs][num_seqs][width] fp32
+  int num_slabs;
+  int64_t slab_stride;
+  const uint16_t* bias;       // FUSE == 2: [width] or null
+  const uint16_t* cos_sin;    // [max_position][D]: cos | sin halves
+  int max_position;
+  const int64_t* slots;       // [num_seqs]; < 0 or beyond the pool: not stored
+};
+
+// 8 consecutive elements of the projection row of `seq` starting at column `col`: the loads
+// (issue) are separate from the arithmetic (finish) so that a caller can put every load of a
+// prologue in flight before the first value is used.  SLABS > 0: the slab count is a
+// compile-time constant (straight-line loads); SLABS == 0: any count, loaded in finish().
+template <typename T, int FUSE, int SLABS>
+struct Proj8 {
+  static constexpr int S = SLABS > 0 ? SLABS : 1;
+  float4 a[S], b[S];
+  uint4 raw;      // FUSE == 1: the 16-bit row; FUSE == 2: the bias (or a dummy)
+  float has;
+  const float* pr;
+
+  __device__ __forceinline__ void issue(const uint16_t* q, int64_t q_stride, const RopeArgs& ra, int seq, int width,
+                                        int col) {
+    if (FUSE == 2) {
+      pr = ra.partial + static_cast<int64_t>(seq) * width + col;
+      if (SLABS > 0) {
+#pragma unroll
+        for (int s = 0; s < SLABS; ++s) {
+          const float4* p = reinterpret_cast<const float4*>(pr + s * ra.slab_stride);
+          a[s] = p[0];
+          b[s] = p[1];
+        }
+      }
+      // branch-free (a branch around a load drains the load queue): without a bias the load
+      // goes to the start of the cos/sin table and is multiplied by zero
+      has = ra.bias != nullptr ? 1.f : 0.f;
+      raw = *reinterpret_cast<const uint4*>(ra.bias != nullptr ? ra.bias + col : ra.cos_sin);
+    } else {
+      raw = *reinterpret_cast<const uint4*>(q + static_cast<int64_t>(seq) * q_stride + col);
+    }
+  }
+  __device__ __forceinline__ void finish(float (&f)[8], const RopeArgs& ra) const {
+    if (FUSE == 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = 0.f;
+      if (SLABS > 0) {
+#pragma unroll
+        for (int s = 0; s < SLABS; ++s) {
+          f[0] += a[s].x; f[1] += a[s].y; f[2] += a[s].z; f[3] += a[s].w;
+          f[4] += b[s].x; f[5] += b[s].y; f[6] += b[s].z; f[7] += b[s].w;
+        }
+      } else {
+        for (int s = 0; s < ra.num_slabs; ++s) {
+          const float4* p = reinterpret_cast<const float4*>(pr + s * ra.slab_stride);
+          const float4 x = p[0], y = p[1];
+          f[0] += x.x; f[1] += x.y; f[2] += x.z; f[3] += x.w;
+          f[4] += y.x; f[5] += y.y; f[6] += y.z; f[7] += y.w;
+        }
+      }
+      float bb[8];
+      unpack8<T>(raw, bb);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = round_f<T>(f[j] + has * bb[j]);
+    } else {
+      unpack8<T>(raw, f);
+    }
+  }
+};
+
+// one element of the projection row, as a 16-bit word
+template <typename T, int FUSE, int SLABS>
+__device__ __forceinline__ uint16_t load_proj1(const uint16_t* q, int64_t q_stride, const RopeArgs& ra, int seq,
+                                               int width, int col) {
+  if (FUSE == 2) {
+    const float* pr = ra.partial + static_cast<int64_t>(seq) * width + col;
+    float f = 0.f;
+    if (SLABS > 0) {
+      float v[SLABS > 0 ? SLABS : 1];
+#pragma unroll
+      for (int s = 0; s < SLABS; ++s) v[s] = pr[s * ra.slab_stride];
+#pragma unroll
+      for (int s = 0; s < SLABS; ++s) f += v[s];
+    } else {
+      for (int s = 0; s < ra.num_slabs; ++s) f += pr[s * ra.slab_stride];
+    }
+    f += (ra.bias != nullptr ? 1.f : 0.f) * T::to_f(*(ra.bias != nullptr ? ra.bias + col : ra.cos_sin));
+    return T::from_f(f);
+  }
+  return q[static_cast<int64_t>(seq) * q_stride + col];
+}
+
+// rotate-half rotation of 8 pairs; every product and the sum rounded to the 16-bit type
+template <typename T>
+__device__ __forceinline__ void rotate8(const float (&x1)[8], const float (&x2)[8], const float (&co)[8],
+                                        const float (&si)[8], float (&o1)[8], float (&o2)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    // contraction off: with fp16 the compiler would lower to half arithmetic and fuse mul + sub into one fma
+#pragma clang fp contract(off)
+    o1[j] = round_f<T>(x1[j] * co[j]) - round_f<T>(x2[j] * si[j]);
+    o2[j] = round_f<T>(x2[j] * co[j]) + round_f<T>(x1[j] * si[j]);
+  }
+}
+
+template <typename T, int D, int FUSE, int SLABS>
 __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
     uint16_t* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_ml,
-    const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ k_cache,
-    const uint16_t* __restrict__ v_cache, int num_blocks, const int32_t* __restrict__ block_tables,
+    const uint16_t* __restrict__ q, int64_t q_stride, uint16_t* k_cache,
+    uint16_t* v_cache, int num_blocks, const int32_t* __restrict__ block_tables,
     int max_blocks, const int32_t* __restrict__ context_lens, int num_heads, int num_kv_heads,
-    float scale_log2e, int num_splits) {
+    float scale_log2e, int num_splits, RopeArgs ra) {
   constexpr int KS = D / 32;  // MFMA k-steps over head_dim for QK^T
   constexpr int NT = D / 16;  // 16-row tiles of head_dim for PV
   constexpr int BS = MI355_BLOCK_SIZE;
@@ -60,38 +176,18 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
   const int t_begin = split * per_split;
   const int t_end = min(ctx, t_begin + per_split);
 
-  // Q fragments (B operand): column c = head within the group
-  uint4 qf[KS];
-  if (c < group) {
-    const uint16_t* qp = q + seq * q_stride + static_cast<int64_t>(kvh * group + c) * D + 8 * h;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(qp + 32 * ks);
-  } else {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = make_uint4(0, 0, 0, 0);
-  }
-
-  float m = -INFINITY, l = 0.f;
-  f32x4 o[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   const int32_t* bt = block_tables + static_cast<int64_t>(seq) * max_blocks;
   const int last_blk_idx = ctx > 0 ? (ctx - 1) / BS : 0;
   const int koff = ((c >> 2) & 1) * 8 + (c & 3);  // token row inside the page for tile "a"
 
-  for (int tb = t_begin + kStep * wave; tb < t_end; tb += kStep * kDecodeWaves) {
-    const int bi = tb / BS;
-    int blk0 = bt[bi];
-    int blk1 = bt[min(bi + 1, last_blk_idx)];
+  // ---- loads of one 32-token step: K tiles a/b, then the V tiles
+  uint4 ka[KS], kb[KS], vf[NT];
+  auto issue_page_loads = [&](int blk0, int blk1) {
     blk0 = min(max(blk0, 0), num_blocks - 1);
     blk1 = min(max(blk1, 0), num_blocks - 1);
-
-    // ---- issue all loads of the step: K tiles a/b, then the V tiles
     const int kblk = (c & 8) ? blk1 : blk0;
     const uint16_t* kp =
         k_cache + ((static_cast<int64_t>(kblk) * num_kv_heads + kvh) * BS + koff) * D + 8 * h;
-    uint4 ka[KS], kb[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       ka[ks] = *reinterpret_cast<const uint4*>(kp + 32 * ks);
@@ -100,9 +196,138 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
     const int vblk = (h & 2) ? blk1 : blk0;
     const uint16_t* vp =
         v_cache + ((static_cast<int64_t>(vblk) * num_kv_heads + kvh) * D + c) * BS + 8 * (h & 1);
-    uint4 vf[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) vf[n] = *reinterpret_cast<const uint4*>(vp + n * 16 * BS);
+  };
+  auto issue_loads = [&](int tb) {
+    const int bi = min(tb / BS, last_blk_idx);
+    issue_page_loads(bt[bi], bt[min(bi + 1, last_blk_idx)]);
+  };
+  int tb = t_begin + kStep * wave;
+  // The loads of the wave's first step are in flight while the query is prepared.  They are
+  // unconditional (a wave without tokens loads a valid page it never uses): a load inside a
+  // branch makes the compiler drain the load queue at the join, which would put the page loads
+  // and the query's loads one after the other.  Without splits the first step's block-table
+  // entries do not depend on the context length, so their load starts together with the
+  // context-length load instead of after it: one dependent memory round trip less.
+  if (num_splits == 1) {
+    const int bi = min(2 * wave, max_blocks - 1);
+    issue_page_loads(bt[bi], bt[min(bi + 1, max_blocks - 1)]);
+  } else {
+    issue_loads(tb);
+  }
+
+  // Q fragments (B operand): column c = head within the group
+  uint4 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = make_uint4(0, 0, 0, 0);
+  // fused form: the new token's rotated k row in fragment order, and v[16n + c]
+  uint4 knew[FUSE ? KS : 1];
+  uint16_t vnew[FUSE ? NT : 1];
+  const int t_new = FUSE ? ctx - 1 : -1;       // patched into the step that covers it
+  if (FUSE == 0) {
+    if (c < group) {
+      const uint16_t* qp = q + seq * q_stride + static_cast<int64_t>(kvh * group + c) * D + 8 * h;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(qp + 32 * ks);
+    }
+  } else {
+    const int width = (num_heads + 2 * num_kv_heads) * D;
+    // the new token sits at position ctx - 1: no separate position array, no extra dependent load
+    int64_t pos = ctx - 1;
+    pos = pos < 0 ? 0 : (pos >= ra.max_position ? ra.max_position - 1 : pos);
+    const uint16_t* cs = ra.cos_sin + pos * D;
+    const bool owner = ctx > 0 && t_new >= t_begin && t_new < t_begin + per_split;
+    const int kcol = (num_heads + kvh) * D, vcol = (num_heads + num_kv_heads + kvh) * D;
+    // Every load of the prologue goes out before the first value is used, in straight-line code
+    // (lanes beyond the group and workgroups that do not own the new token compute values they
+    // drop): the rotation then waits once, not once per branch or per chunk.
+    const int hq = c < group ? c : 0;
+    const int64_t slot = ra.slots[seq];
+    Proj8<T, FUSE, SLABS> pq1[KS / 2], pq2[KS / 2], pk1[KS / 2], pk2[KS / 2];
+    uint4 cosr[KS / 2], sinr[KS / 2];
+#pragma unroll
+    for (int ks = 0; ks < KS / 2; ++ks) {
+      cosr[ks] = *reinterpret_cast<const uint4*>(cs + 32 * ks + 8 * h);
+      sinr[ks] = *reinterpret_cast<const uint4*>(cs + D / 2 + 32 * ks + 8 * h);
+      const int col = (kvh * group + hq) * D + 8 * h + 32 * ks;
+      pq1[ks].issue(q, q_stride, ra, seq, width, col);
+      pq2[ks].issue(q, q_stride, ra, seq, width, col + D / 2);
+      pk1[ks].issue(q, q_stride, ra, seq, width, kcol + 8 * h + 32 * ks);   // the k row: one more "head"
+      pk2[ks].issue(q, q_stride, ra, seq, width, kcol + 8 * h + 32 * ks + D / 2);
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) vnew[n] = load_proj1<T, FUSE, SLABS>(q, q_stride, ra, seq, width, vcol + 16 * n + c);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS / 2; ++ks) {
+      float co[8], si[8], x1[8], x2[8], o1[8], o2[8];
+      unpack8<T>(cosr[ks], co);
+      unpack8<T>(sinr[ks], si);
+      pq1[ks].finish(x1, ra);
+      pq2[ks].finish(x2, ra);
+      rotate8<T>(x1, x2, co, si, o1, o2);
+      if (c < group) {
+        qf[ks] = pack8<T>(o1);
+        qf[ks + KS / 2] = pack8<T>(o2);
+      }
+      pk1[ks].finish(x1, ra);
+      pk2[ks].finish(x2, ra);
+      rotate8<T>(x1, x2, co, si, o1, o2);
+      knew[ks] = pack8<T>(o1);
+      knew[ks + KS / 2] = pack8<T>(o2);
+    }
+    if (owner) {
+      // the pages get the new token too (for the steps to come); nobody in this launch waits for it
+      if (slot >= 0 && slot < static_cast<int64_t>(num_blocks) * BS && wave == 0) {
+        const int64_t blk = slot / BS;
+        const int off = static_cast<int>(slot % BS);
+        if (c == 0) {                                // lanes h = 0..3 hold the whole k row between them
+          uint16_t* dst = k_cache + ((blk * num_kv_heads + kvh) * BS + off) * D + 8 * h;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) *reinterpret_cast<uint4*>(dst + 32 * ks) = knew[ks];
+        }
+        if (h == 0) {                                // lanes c = 0..15 hold v[16n + c]
+          uint16_t* dst = v_cache + (blk * num_kv_heads + kvh) * D * BS + off;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) dst[static_cast<int64_t>(16 * n + c) * BS] = vnew[n];
+        }
+      }
+    }
+  }
+
+  float m = -INFINITY, l = 0.f;
+  f32x4 o[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  while (tb < t_end) {
+    if (FUSE != 0 && t_new >= tb && t_new < tb + kStep) {
+      // the new token's k row / v column come from registers, whatever the pages held
+      const int r = t_new - tb;
+      const int ta = 16 * (c >> 3) + koff;           // token of this lane's row in tile a; tile b: + 4
+      if (r == ta) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) ka[ks] = knew[ks];
+      }
+      if (r == ta + 4) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kb[ks] = knew[ks];
+      }
+      if ((r >> 3) == h) {                           // this lane's 8 tokens are 8h .. 8h + 7
+        const int j = r & 7;
+        const uint32_t keep = (j & 1) ? 0x0000FFFFu : 0xFFFF0000u;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const uint32_t ins = static_cast<uint32_t>(vnew[n]) << ((j & 1) * 16);
+          uint32_t w[4] = {vf[n].x, vf[n].y, vf[n].z, vf[n].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e == (j >> 1)) w[e] = (w[e] & keep) | ins;
+          vf[n] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+      }
+    }
 
     // ---- S^T = K . Q^T
     f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
@@ -157,6 +382,9 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
     // ---- O^T += V^T . P^T
 #pragma unroll
     for (int n = 0; n < NT; ++n) o[n] = T::mfma(vf[n], pf, o[n]);
+
+    tb += kStep * kDecodeWaves;
+    if (tb < t_end) issue_loads(tb);
   }
 
   // column sums live on the 4 lanes (c, h = 0..3)
@@ -228,12 +456,12 @@ __global__ __launch_bounds__(D) void paged_attn_merge_kernel(uint16_t* __restric
   out[row * D + d] = T::from_f(lsum > 0.f ? acc / lsum : 0.f);
 }
 
-template <typename T, int D>
-static int32_t launch_decode(void* out, const void* q, int64_t q_stride, const void* k_cache,
-                             const void* v_cache, int32_t num_blocks, const int32_t* block_tables,
+template <typename T, int D, int FUSE, int SLABS = 0>
+static int32_t launch_decode(void* out, const void* q, int64_t q_stride, void* k_cache,
+                             void* v_cache, int32_t num_blocks, const int32_t* block_tables,
                              int32_t max_blocks, const int32_t* context_lens, int32_t num_seqs,
                              int32_t num_heads, int32_t num_kv_heads, float scale, int32_t num_splits,
-                             void* workspace, hipStream_t s) {
+                             void* workspace, hipStream_t s, const RopeArgs& ra) {
   float* part_o = nullptr;
   float* part_ml = nullptr;
   if (num_splits > 1) {
@@ -241,11 +469,11 @@ static int32_t launch_decode(void* out, const void* q, int64_t q_stride, const v
     part_ml = part_o + static_cast<int64_t>(num_seqs) * num_heads * num_splits * D;
   }
   dim3 grid(num_seqs, num_kv_heads, num_splits), block(kDecodeThreads);
-  hipLaunchKernelGGL((paged_attn_decode_kernel<T, D>), grid, block, 0, s, static_cast<uint16_t*>(out),
+  hipLaunchKernelGGL((paged_attn_decode_kernel<T, D, FUSE, SLABS>), grid, block, 0, s, static_cast<uint16_t*>(out),
                      part_o, part_ml, static_cast<const uint16_t*>(q), q_stride,
-                     static_cast<const uint16_t*>(k_cache), static_cast<const uint16_t*>(v_cache),
+                     static_cast<uint16_t*>(k_cache), static_cast<uint16_t*>(v_cache),
                      num_blocks, block_tables, max_blocks, context_lens, num_heads, num_kv_heads,
-                     scale * 1.4426950408889634f, num_splits);
+                     scale * 1.4426950408889634f, num_splits, ra);
   int32_t rc = check_launch("mi355_paged_attn_decode");
   if (rc != MI355_OK || num_splits == 1) return rc;
   hipLaunchKernelGGL((paged_attn_merge_kernel<T, D>), dim3(num_seqs * num_heads), dim3(D), 0, s,
@@ -261,16 +489,15 @@ extern "C" int64_t mi355_paged_attn_decode_workspace(int32_t num_seqs, int32_t n
   return static_cast<int64_t>(num_seqs) * num_heads * num_splits * (head_dim + 2) * sizeof(float);
 }
 
-extern "C" int32_t mi355_paged_attn_decode(void* out, const void* q, int64_t q_stride, const void* k_cache,
-                                           const void* v_cache, int32_t num_blocks,
-                                           const int32_t* block_tables, int32_t max_blocks_per_seq,
-                                           const int32_t* context_lens, int32_t num_seqs,
-                                           int32_t num_heads, int32_t num_kv_heads, int32_t head_dim,
-                                           float scale, int32_t num_splits, void* workspace,
-                                           int64_t workspace_bytes, int32_t dtype, void* stream) {
-  using namespace mi355;
-  const char* name = "mi355_paged_attn_decode";
-  MI355_REQUIRE(out && q && k_cache && v_cache && block_tables && context_lens, MI355_ERR_INVALID,
+namespace mi355 {
+
+static int32_t decode_entry(const char* name, void* out, const void* q, int64_t q_stride, void* k_cache,
+                            void* v_cache, int32_t num_blocks, const int32_t* block_tables,
+                            int32_t max_blocks_per_seq, const int32_t* context_lens, int32_t num_seqs,
+                            int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, float scale,
+                            int32_t num_splits, void* workspace, int64_t workspace_bytes, int32_t dtype,
+                            void* stream, int fuse, const RopeArgs& ra) {
+  MI355_REQUIRE(out && k_cache && v_cache && block_tables && context_lens && (q || fuse == 2), MI355_ERR_INVALID,
                 "%s: null pointer", name);
   MI355_REQUIRE(num_seqs >= 0 && num_blocks > 0 && max_blocks_per_seq > 0, MI355_ERR_INVALID,
                 "%s: num_seqs/num_blocks/max_blocks_per_seq out of range", name);
@@ -283,12 +510,26 @@ extern "C" int32_t mi355_paged_attn_decode(void* out, const void* q, int64_t q_s
                 "%s: num_kv_heads <= 65535 and 1 <= num_splits <= 64 required", name);
   MI355_REQUIRE(head_dim == 64 || head_dim == 128, MI355_ERR_UNSUPPORTED,
                 "%s: head_dim %d not supported (64 or 128)", name, head_dim);
-  MI355_REQUIRE(q_stride >= static_cast<int64_t>(num_heads) * head_dim && q_stride % 8 == 0,
-                MI355_ERR_INVALID, "%s: q_stride %lld invalid", name, (long long)q_stride);
-  MI355_REQUIRE(aligned16(out) && aligned16(q) && aligned16(k_cache) && aligned16(v_cache),
-                MI355_ERR_INVALID, "%s: pointers must be 16-byte aligned", name);
+  const int64_t width = static_cast<int64_t>(num_heads + (fuse ? 2 * num_kv_heads : 0)) * head_dim;
+  if (fuse != 2)
+    MI355_REQUIRE(q_stride >= width && q_stride % 8 == 0 && aligned16(q), MI355_ERR_INVALID,
+                  "%s: q_stride %lld invalid or q misaligned", name, (long long)q_stride);
+  MI355_REQUIRE(aligned16(out) && aligned16(k_cache) && aligned16(v_cache), MI355_ERR_INVALID,
+                "%s: pointers must be 16-byte aligned", name);
   MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED,
                 "%s: dtype %d not supported (bf16/fp16 only)", name, dtype);
+  if (fuse) {
+    MI355_REQUIRE(ra.cos_sin && ra.slots && ra.max_position > 0 && aligned16(ra.cos_sin), MI355_ERR_INVALID,
+                  "%s: cos_sin / slot_mapping missing or misaligned", name);
+    if (fuse == 2) {
+      MI355_REQUIRE(ra.partial && aligned16(ra.partial) && (ra.bias == nullptr || aligned16(ra.bias)),
+                    MI355_ERR_INVALID, "%s: partial missing or partial/bias misaligned", name);
+      MI355_REQUIRE(ra.num_slabs >= 1 && ra.num_slabs <= 64 && ra.slab_stride >= num_seqs * width &&
+                        ra.slab_stride % 4 == 0,
+                    MI355_ERR_INVALID, "%s: num_slabs in [1, 64] and slab_stride >= num_seqs * width (multiple of 4) required",
+                    name);
+    }
+  }
   if (num_splits > 1) {
     const int64_t need = mi355_paged_attn_decode_workspace(num_seqs, num_heads, head_dim, num_splits);
     MI355_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= need, MI355_ERR_INVALID,
@@ -297,15 +538,59 @@ extern "C" int32_t mi355_paged_attn_decode(void* out, const void* q, int64_t q_s
   }
   if (num_seqs == 0) return MI355_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define MI355_DEC(TT, DD)                                                                              \
-  return launch_decode<TT, DD>(out, q, q_stride, k_cache, v_cache, num_blocks, block_tables,          \
-                               max_blocks_per_seq, context_lens, num_seqs, num_heads, num_kv_heads,   \
-                               scale, num_splits, workspace, s)
+#define MI355_DEC(TT, DD, FF, SS)                                                                          \
+  return launch_decode<TT, DD, FF, SS>(out, q, q_stride, k_cache, v_cache, num_blocks, block_tables,      \
+                                       max_blocks_per_seq, context_lens, num_seqs, num_heads, num_kv_heads, \
+                                       scale, num_splits, workspace, s, ra)
+#define MI355_DEC_F(TT, DD)                                 \
+  do {                                                      \
+    if (fuse == 0) MI355_DEC(TT, DD, 0, 0);                 \
+    if (fuse == 1) MI355_DEC(TT, DD, 1, 0);                 \
+    if (ra.num_slabs == 1) MI355_DEC(TT, DD, 2, 1);         \
+    if (ra.num_slabs == 2) MI355_DEC(TT, DD, 2, 2);         \
+    if (ra.num_slabs == 4) MI355_DEC(TT, DD, 2, 4);         \
+    if (ra.num_slabs == 8) MI355_DEC(TT, DD, 2, 8);         \
+    MI355_DEC(TT, DD, 2, 0);                                \
+  } while (0)
   if (dtype == MI355_BF16) {
-    if (head_dim == 64) MI355_DEC(BF16, 64);
-    MI355_DEC(BF16, 128);
+    if (head_dim == 64) MI355_DEC_F(BF16, 64);
+    MI355_DEC_F(BF16, 128);
   }
-  if (head_dim == 64) MI355_DEC(F16, 64);
-  MI355_DEC(F16, 128);
+  if (head_dim == 64) MI355_DEC_F(F16, 64);
+  MI355_DEC_F(F16, 128);
+#undef MI355_DEC_F
 #undef MI355_DEC
+}
+
+}  // namespace mi355
+
+extern "C" int32_t mi355_paged_attn_decode(void* out, const void* q, int64_t q_stride, const void* k_cache,
+                                           const void* v_cache, int32_t num_blocks,
+                                           const int32_t* block_tables, int32_t max_blocks_per_seq,
+                                           const int32_t* context_lens, int32_t num_seqs,
+                                           int32_t num_heads, int32_t num_kv_heads, int32_t head_dim,
+                                           float scale, int32_t num_splits, void* workspace,
+                                           int64_t workspace_bytes, int32_t dtype, void* stream) {
+  // the caches are only read in this form
+  return mi355::decode_entry("mi355_paged_attn_decode", out, q, q_stride, const_cast<void*>(k_cache),
+                             const_cast<void*>(v_cache), num_blocks, block_tables, max_blocks_per_seq, context_lens,
+                             num_seqs, num_heads, num_kv_heads, head_dim, scale, num_splits, workspace,
+                             workspace_bytes, dtype, stream, 0, mi355::RopeArgs{});
+}
+
+extern "C" int32_t mi355_paged_attn_decode_fused(void* out, const void* qkv, int64_t qkv_stride,
+                                                 const float* partial, int32_t num_slabs, int64_t slab_stride,
+                                                 const void* bias, const void* cos_sin,
+                                                 int32_t max_position, const int64_t* slot_mapping, void* k_cache,
+                                                 void* v_cache, int32_t num_blocks, const int32_t* block_tables,
+                                                 int32_t max_blocks_per_seq, const int32_t* context_lens,
+                                                 int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads,
+                                                 int32_t head_dim, float scale, int32_t num_splits, void* workspace,
+                                                 int64_t workspace_bytes, int32_t dtype, void* stream) {
+  const mi355::RopeArgs ra{partial, num_slabs, slab_stride, static_cast<const uint16_t*>(bias),
+                           static_cast<const uint16_t*>(cos_sin), max_position, slot_mapping};
+  return mi355::decode_entry("mi355_paged_attn_decode_fused", out, qkv, qkv_stride, k_cache, v_cache, num_blocks,
+                             block_tables, max_blocks_per_seq, context_lens, num_seqs, num_heads, num_kv_heads,
+                             head_dim, scale, num_splits, workspace, workspace_bytes, dtype, stream,
+                             partial != nullptr ? 2 : 1, ra);
 }

@@ -191,11 +191,10 @@ class ModelRunner:
             else:
                 ops.fused_add_rms_norm_partial(self.part_dn, gd, resid, lw.input_norm, self.eps, x)
             ops.linear_tiled(x, tw["qkv"], self.qw, partial=self.part_qkv, tiles_per_wg=tq, k_groups=gq, epilogue=P)
-            ops.rope_kv_write(qkv, pos, self.cos_sin, slots, self.k_cache[i], self.v_cache[i], self.nh, self.nkv,
-                              self.d, partial=self.part_qkv, num_slabs=gq, bias=lw.qkv_b)
-            ops.paged_attn_decode(qkv[:, : self.nh * self.d], self.k_cache[i], self.v_cache[i], bt, ctx,
-                                  self.nh, self.nkv, self.d, self.scale, num_splits=splits,
-                                  workspace=self.attn_ws, out=attn)
+            ops.paged_attn_decode_fused(None, self.cos_sin, slots, self.k_cache[i], self.v_cache[i], bt, ctx,
+                                        self.nh, self.nkv, self.d, self.scale, num_splits=splits,
+                                        workspace=self.attn_ws, out=attn, partial=self.part_qkv, num_slabs=gq,
+                                        bias=lw.qkv_b)
             if self.tp_size == 1:
                 to, go = plans["o"]
                 ops.linear_tiled(attn, tw["o"], self.H, partial=self.part_o, tiles_per_wg=to, k_groups=go, epilogue=P)
@@ -269,11 +268,9 @@ class ModelRunner:
             return
 
         def attend(i, qkv_, attn_):
-            ops.rope_kv_write(qkv_, pos, self.cos_sin, slots, self.k_cache[i], self.v_cache[i],
-                              self.nh, self.nkv, self.d)
-            ops.paged_attn_decode(qkv_[:, : self.nh * self.d], self.k_cache[i], self.v_cache[i], bt, ctx,
-                                  self.nh, self.nkv, self.d, self.scale, num_splits=splits,
-                                  workspace=self.attn_ws, out=attn_)
+            ops.paged_attn_decode_fused(qkv_, self.cos_sin, slots, self.k_cache[i], self.v_cache[i], bt, ctx,
+                                        self.nh, self.nkv, self.d, self.scale, num_splits=splits,
+                                        workspace=self.attn_ws, out=attn_)
 
         last = self._layers(b, resid, x, qkv, attn, o, gu, act, dn, attend)
         ops.fused_add_rms_norm(last, resid, self.w.final_norm, self.eps, out=x)

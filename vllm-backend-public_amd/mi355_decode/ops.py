@@ -185,6 +185,60 @@ def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
     return out
 
 
+def paged_attn_decode_fused(qkv: torch.Tensor | None, cos_sin: torch.Tensor, slot_mapping: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                            block_tables: torch.Tensor, context_lens: torch.Tensor, num_heads: int,
+                            num_kv_heads: int, head_dim: int, scale: float, num_splits: int = 1,
+                            workspace: torch.Tensor | None = None, out: torch.Tensor | None = None,
+                            partial: torch.Tensor | None = None, num_slabs: int = 0,
+                            bias: torch.Tensor | None = None):
+    """rope_kv_write + paged_attn_decode in one launch; the new token of a sequence is
+    the one at position context_lens - 1.  The step's projection is either
+    ``qkv`` (packed 16-bit rows [num_seqs, (nh + 2 nkv) d], left untouched) or ``partial``
+    (fp32 [num_slabs, num_seqs, width] from linear_tiled, + ``bias``)."""
+    B = slot_mapping.numel()
+    width = (num_heads + 2 * num_kv_heads) * head_dim
+    if partial is None:
+        dt = _dt16(qkv, "qkv")
+        if qkv.shape != (B, width):
+            raise ValueError("qkv must be [num_seqs, (num_heads + 2*num_kv_heads) * head_dim]")
+        ref = qkv
+    else:
+        dt = _dt16(k_cache, "k_cache")
+        _check_partial(partial, num_slabs, B, width)
+        if bias is not None and (bias.dtype != k_cache.dtype or bias.numel() != width or not bias.is_contiguous()):
+            raise ValueError("bias must be contiguous [width] in the cache dtype")
+        ref = k_cache
+    nb = _check_cache(ref, k_cache, v_cache, block_tables, num_kv_heads, head_dim)
+    _dev(slot_mapping, "slot_mapping")
+    if slot_mapping.dtype != torch.int64 or not slot_mapping.is_contiguous():
+        raise ValueError("slot_mapping must be contiguous int64 [num_seqs]")
+    _dev(context_lens, "context_lens")
+    if context_lens.dtype != torch.int32 or context_lens.numel() != B or not context_lens.is_contiguous():
+        raise ValueError("context_lens must be contiguous int32 [num_seqs]")
+    if block_tables.shape[0] != B:
+        raise ValueError("block_tables rows must equal num_seqs")
+    if cos_sin.dtype != ref.dtype or cos_sin.dim() != 2 or cos_sin.shape[1] != head_dim or not cos_sin.is_contiguous():
+        raise ValueError("cos_sin must be contiguous [max_position, head_dim] in the model dtype")
+    if out is None:
+        out = torch.empty((B, num_heads * head_dim), dtype=ref.dtype, device=ref.device)
+    elif not out.is_contiguous() or out.numel() != B * num_heads * head_dim or out.dtype != ref.dtype:
+        raise ValueError("out must be contiguous [num_seqs, num_heads*head_dim]")
+    ws_ptr, ws_bytes = 0, 0
+    if num_splits > 1:
+        need = decode_workspace_bytes(B, num_heads, head_dim, num_splits)
+        if workspace is None:
+            workspace = torch.empty(need, dtype=torch.uint8, device=ref.device)
+        ws_ptr, ws_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    check(lib.mi355_paged_attn_decode_fused(
+        out.data_ptr(), qkv.data_ptr() if qkv is not None else 0, _rows(qkv, "qkv") if qkv is not None else 0,
+        partial.data_ptr() if partial is not None else 0, num_slabs, B * width,
+        bias.data_ptr() if bias is not None else 0, cos_sin.data_ptr(), cos_sin.shape[0],
+        slot_mapping.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), nb, block_tables.data_ptr(),
+        block_tables.shape[1], context_lens.data_ptr(), B, num_heads, num_kv_heads, head_dim, float(scale),
+        num_splits, ws_ptr, ws_bytes, dt, _stream()))
+    return out
+
+
 def paged_attn_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                        block_tables: torch.Tensor, cu_seqlens: torch.Tensor, context_lens: torch.Tensor,
                        max_q_len: int, num_heads: int, num_kv_heads: int, head_dim: int, scale: float,
