@@ -724,7 +724,7 @@ def test_linear_tiled_rejects_unbuilt_geometries(ops):
     wt = ops.tile_weights(torch.zeros(64, 1024, dtype=torch.bfloat16, device="cuda"))
     with pytest.raises(Mi355Error, match="no kernel for M 128"):
         ops.linear_tiled(x, wt, 64, tiles_per_wg=4)
-    with pytest.raises(Mi355Error, match="even number"):
+    with pytest.raises(Mi355Error, match="multiple of 512"):
         ops.linear_tiled(x[:, :768].contiguous(), ops.tile_weights(torch.zeros(64, 768, dtype=torch.bfloat16, device="cuda")),
                          64, tiles_per_wg=8)
     with pytest.raises(Mi355Error, match="outside"):
@@ -785,3 +785,37 @@ def test_paged_attn_decode_fused(ops, dtype, nh, kvh, d, splits, slabs):
     attn_close(host(out2).reshape(n, nh, d), ref, dtype)
     np.testing.assert_array_equal(host(kc2), kc_ref)
     np.testing.assert_array_equal(host(vc2), vc_ref)
+
+
+def _k_ranges(K, unit, groups):
+    """K range of every group: units of `unit` dealt out as evenly as they go, larger groups first."""
+    units = K // unit
+    base, rem = divmod(units, groups)
+    out, start = [], 0
+    for g in range(groups):
+        n = (base + (1 if g < rem else 0)) * unit
+        out.append((start, start + n))
+        start += n
+    return out
+
+
+@pytest.mark.parametrize("M,N,K,tiles,groups,unit", [(32, 3584, 3584, 104, 3, 512), (64, 3584, 18944, 104, 4, 512),
+                                                     (16, 512, 7168, 8, 3, 1024), (128, 1024, 18944, 8, 5, 512),
+                                                     (20, 256, 2560, 104, 5, 512)])
+def test_linear_tiled_uneven_k_split(ops, M, N, K, tiles, groups, unit):
+    """K / slice is not a multiple of the group count (Qwen2-7B: 3584 = 7 x 512, 18944 = 37 x 512)."""
+    dtype = "bfloat16"
+    rng = rng_for("tiled-uneven", M, N, K, groups)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (N, K), dtype, 0.05)
+    wt, xd = ops.tile_weights(dev(w, dtype)), dev(x, dtype)
+    part = ops.linear_tiled(xd, wt, N, k_groups=groups, epilogue=ops.EPI_PARTIAL, tiles_per_wg=tiles).cpu().numpy()
+    for g, (a, b) in enumerate(_k_ranges(K, unit, groups)):
+        ref = x[:, a:b].astype(np.float64) @ w[:, a:b].astype(np.float64).T
+        np.testing.assert_allclose(part[g], ref, rtol=1e-4, atol=2e-3)
+    ref64 = x.astype(np.float64) @ w.astype(np.float64).T
+    y = _slab_sum(part, None, dtype)
+    assert (np.abs(y - ref64) <= _linear_tol(ref64, x, w, K, dtype)).all()
+    counters = torch.zeros(_groups(N, tiles), dtype=torch.int32, device="cuda")
+    y2 = ops.linear_tiled_fused(xd, wt, N, tiles_per_wg=tiles, k_groups=groups, epilogue=ops.EPI_REDUCE_STORE,
+                                counters=counters)
+    np.testing.assert_array_equal(host(y2), y)

@@ -63,7 +63,7 @@ template <typename T, int MT, int NW, int KSL, int EPI, bool NORM>
 __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
     uint16_t* __restrict__ y, float* __restrict__ partial, const uint16_t* __restrict__ x,
     const uint16_t* __restrict__ wt, const uint16_t* __restrict__ bias, int M, int N, int K,
-    int64_t x_stride, int64_t y_stride, int tiles_total, int phases_per_group, FusedArgs fa) {
+    int64_t x_stride, int64_t y_stride, int tiles_total, int phases_total, FusedArgs fa) {
   constexpr int ROWS = MT * 16;
   constexpr int U = kTU;
   constexpr int NT = NW * 64;
@@ -72,6 +72,9 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   constexpr int G = KSL / 32 / U;          // register groups per phase (8, 4 or 2)
   constexpr int D = 4;                     // ring depth
   constexpr int PU = G >= D ? 1 : D / G;   // phases per main-loop iteration: ring slots stay compile-time
+  const int units = phases_total / PU, ubase = units / static_cast<int>(gridDim.y), urem = units % static_cast<int>(gridDim.y);
+  const int P = (ubase + (static_cast<int>(blockIdx.y) < urem ? 1 : 0)) * PU;
+  const int p0 = (static_cast<int>(blockIdx.y) * ubase + min(static_cast<int>(blockIdx.y), urem)) * PU;
   static_assert((PU * G) % D == 0, "ring slots must repeat every main-loop iteration");
   static_assert(!NORM || MT <= 2, "the norm prologue is built for M <= 32");
   static_assert(EPI != EPI_REDUCE_RESID || MT <= 2, "the sum-of-squares table has 32 rows");
@@ -86,8 +89,9 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   const int tile_raw = blockIdx.x * NW + wave;
   const int tile = min(tile_raw, tiles_total - 1);
   const int kgroup = blockIdx.y;
-  const int P = phases_per_group;
-  const int p0 = kgroup * P;               // first phase of this workgroup
+  // K range of this workgroup: the slices are dealt to the K groups in units of PU (the
+  // main loop's stride), the first `rem` groups taking one unit more -- any group count up to
+  // the unit count works, K need not divide evenly
 
   // ---- x slice staging: 16-byte vectors, whole rows, coalesced
   constexpr int NX = ROWS * (KSL / 8) / NT;
@@ -378,10 +382,10 @@ __global__ void tile_weights_kernel(uint16_t* __restrict__ dst, const uint16_t* 
   }
 }
 
-#define MI355_LT_ARGS y, partial, x, wt, bias, M, N, K, xs, ys, tiles_total, ppg
+#define MI355_LT_ARGS y, partial, x, wt, bias, M, N, K, xs, ys, tiles_total, phases
 #define MI355_LT_PARAMS                                                                                       \
   uint16_t *y, float *partial, const uint16_t *x, const uint16_t *wt, const uint16_t *bias, int M, int N, int K, \
-      int64_t xs, int64_t ys, int tiles_total, int ppg
+      int64_t xs, int64_t ys, int tiles_total, int phases
 
 template <typename T, int MT, int NW, int KSL, int EPI, bool NORM>
 static void launch_one(dim3 grid, hipStream_t s, MI355_LT_PARAMS, const FusedArgs& fa) {
@@ -453,12 +457,11 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
   MI355_REQUIRE(N > 0 && K > 0 && K % ksl == 0, MI355_ERR_UNSUPPORTED,
                 "%s: K %d must be a multiple of the x slice %d (M %d)", name, K, ksl, M);
   const int phases = K / ksl;
-  MI355_REQUIRE(k_groups >= 1 && phases % k_groups == 0, MI355_ERR_INVALID, "%s: k_groups %d must divide K/%d = %d",
-                name, k_groups, ksl, phases);
-  const int ppg = phases / k_groups;
-  MI355_REQUIRE(ksl >= 512 || ppg % 2 == 0, MI355_ERR_UNSUPPORTED,
-                "%s: with %d-wide slices every workgroup needs an even number of them (K/%d/k_groups = %d)", name,
-                ksl, ksl, ppg);
+  const int pu = ksl >= 512 ? 1 : 2;   // 256-wide slices are walked two at a time
+  MI355_REQUIRE(phases % pu == 0, MI355_ERR_UNSUPPORTED, "%s: K %d must be a multiple of %d for M %d", name, K,
+                ksl * pu, M);
+  MI355_REQUIRE(k_groups >= 1 && k_groups <= phases / pu, MI355_ERR_INVALID,
+                "%s: k_groups %d outside [1, %d] (K / %d)", name, k_groups, phases / pu, ksl * pu);
   MI355_REQUIRE(k_groups == 1 || epilogue == EPI_PARTIAL || reduce, MI355_ERR_INVALID,
                 "%s: k_groups > 1 needs a partial-sum or reducing epilogue", name);
   MI355_REQUIRE(x_stride >= K && x_stride % 8 == 0 && aligned16(x) && aligned16(w_tiled), MI355_ERR_INVALID,
@@ -499,9 +502,9 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
   auto* bp = static_cast<const uint16_t*>(bias);
   const bool ok = dtype == MI355_BF16
                       ? launch_geometry<BF16>(mt, nw, ksl, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K,
-                                              x_stride, y_stride, tiles_total, ppg, fa)
+                                              x_stride, y_stride, tiles_total, phases, fa)
                       : launch_geometry<F16>(mt, nw, ksl, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K,
-                                             x_stride, y_stride, tiles_total, ppg, fa);
+                                             x_stride, y_stride, tiles_total, phases, fa);
   MI355_REQUIRE(ok, MI355_ERR_UNSUPPORTED,
                 "%s: no kernel for M %d with tiles_per_wg %d, epilogue %d%s (M <= 32: 4/8/104/108, fused forms 8/104; "
                 "M <= 64: 8/104; M <= 128: 8)", name, M, tiles_per_wg, epilogue, norm ? " + norm prologue" : "");

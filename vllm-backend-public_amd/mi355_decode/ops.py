@@ -360,19 +360,20 @@ def plan_linear_tiled(N: int, K: int, split_k: bool, M: int = 32):
         candidates = [104]
     for tiles in candidates:
         ksl = tiled_slice_width(M, tiles)
-        if K % ksl:
+        unit = ksl if ksl >= 512 else 2 * ksl          # 256-wide slices are walked two at a time
+        if K % unit:
             continue
-        phases = K // ksl
+        units = K // unit
         wgs = -(-tiles_total // (tiles % 100))
-        best = None
-        for g in ((1, 2, 4, 7, 8, 14, 16) if split_k and wgs < 160 else (1,)):
-            if phases % g or (ksl < 512 and (phases // g) % 2):
-                continue
-            best = g
-            if wgs * g >= 192:
-                break
-        if best is not None:
-            return tiles, best
+        groups = 1
+        if split_k and wgs < 160:
+            groups = max(1, min(-(-192 // wgs), units, 16))
+            # an even deal of the slices if one is near; otherwise K just does not divide evenly
+            for g in range(groups, min(2 * groups, units, 16) + 1):
+                if units % g == 0:
+                    groups = g
+                    break
+        return tiles, groups
     return None
 
 
