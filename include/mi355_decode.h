@@ -359,6 +359,38 @@ int32_t mi355_linear_tiled_fused(void* y, int64_t y_stride, float* partial,
                                  int64_t residual_stride, float* sumsq_out,
                                  uint32_t* counters, int32_t dtype, void* stream);
 
+/*
+ * fp8 weight copies for the decode GEMM (--quantization fp8, vllm_manager.py:405-407,
+ * vllm_templates.py:75-76): OCP e4m3fn weights with one fp32 scale per weight row,
+ * scale = max|row| / 448, q = fp8_rne(w / scale), laid out in 1 KB blocks of 16
+ * rows x 64 k in MFMA operand order (a lane's 16 bytes are its elements of two
+ * consecutive k-steps).  mi355_tile_weights_fp8 quantises and tiles a row-major
+ * 16-bit [N, K] matrix (K % 64 == 0) into dst (mi355_tiled_weight_fp8_bytes(N, K)
+ * bytes) and writes the scales to scale_tiled (fp32 [ceil(N/16) * 16], in the row
+ * order of the tiles, so with interleave_halves gate and up rows alternate tile
+ * by tile).
+ */
+int64_t mi355_tiled_weight_fp8_bytes(int32_t N, int32_t K);
+int32_t mi355_tile_weights_fp8(void* dst, float* scale_tiled, const void* src,
+                               int32_t N, int32_t K, int32_t interleave_halves,
+                               int32_t dtype, void* stream);
+
+/*
+ * mi355_linear_tiled on fp8 weights (weight-only quantisation: x stays 16-bit).
+ * The weight stream is half the bytes; each lane turns its fp8 elements into the
+ * 16-bit MFMA operand in registers (exact), the products accumulate in fp32, and
+ * the row scale is applied to the accumulator before the epilogue:
+ *   y = round(sum_k x[m,k] q[n,k] * scale[n] (+ bias[n])).
+ * Epilogues 0-2 and geometries as mi355_linear_tiled_fused (tiles_per_wg 8 or 104
+ * up to 64 rows, 8 beyond).
+ */
+int32_t mi355_linear_tiled_w8(void* y, int64_t y_stride, void* partial,
+                              const void* x, int64_t x_stride,
+                              const void* w_tiled_fp8, const float* w_scale,
+                              const void* bias, int32_t M, int32_t N, int32_t K,
+                              int32_t tiles_per_wg, int32_t k_groups,
+                              int32_t epilogue, int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

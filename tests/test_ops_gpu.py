@@ -819,3 +819,83 @@ def test_linear_tiled_uneven_k_split(ops, M, N, K, tiles, groups, unit):
     y2 = ops.linear_tiled_fused(xd, wt, N, tiles_per_wg=tiles, k_groups=groups, epilogue=ops.EPI_REDUCE_STORE,
                                 counters=counters)
     np.testing.assert_array_equal(host(y2), y)
+
+
+# --------------------------------------------------------------------------- #
+# fp8 (e4m3fn) weight-only decode GEMM
+# --------------------------------------------------------------------------- #
+def _untile_fp8(qbytes, N, K):
+    """[tiles][K/64][lane][16] bytes -> [tiles*16, K] codes (lane (i, h): bytes 0-7 are row i's
+    k = 64p + 8h + j, bytes 8-15 its k = 64p + 32 + 8h + j)."""
+    tiles = (N + 15) // 16
+    b = qbytes.reshape(tiles, K // 64, 4, 16, 2, 8)          # tile, pair, h, i, half, j
+    return b.transpose(0, 3, 1, 4, 2, 5).reshape(tiles * 16, K)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("N,K,inter", [(64, 512, False), (1000, 1024, False), (4096, 4096, False), (1536, 1024, True)])
+def test_tile_weights_fp8(ops, dtype, N, K, inter):
+    """Quantise + tile: codes and scales bit-exact against the oracle's e4m3fn rounding."""
+    rng = rng_for("fp8-tile", dtype, N, K)
+    w = grid(rng, (N, K), dtype, 0.05)
+    w[3] = 0.0                                                  # an all-zero row: scale 1, codes 0
+    w[5, 7] = R.round_to(np.float32(3.0), dtype)                # an outlier sets its row's scale
+    q, scale = ops.tile_weights_fp8(dev(w, dtype), interleave_halves=inter)
+    codes = _untile_fp8(q.cpu().numpy(), N, K)
+    vals = R.fp8_e4m3fn_decode_table()[codes]
+    q_ref, s_ref = R.quantize_rows_fp8(w)
+    if inter:                                                   # tiles alternate gate / up rows
+        order = np.concatenate([np.concatenate([np.arange(16 * t, 16 * t + 16), N // 2 + np.arange(16 * t, 16 * t + 16)])
+                                for t in range(N // 32)])
+    else:
+        order = np.arange(N)
+    np.testing.assert_array_equal(scale.cpu().numpy()[: len(order)], s_ref[order])
+    np.testing.assert_array_equal(vals[: len(order)], q_ref[order])
+    assert (vals[len(order):] == 0).all()                       # padding rows
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,N,K,tiles,groups,bias", [(32, 4096, 4096, 104, 4, False), (32, 28672, 4096, 8, 1, False),
+                                                     (7, 1000, 1024, 104, 1, True), (64, 3584, 18944, 104, 4, False),
+                                                     (128, 4608, 3584, 8, 7, True), (1, 64, 512, 104, 1, False),
+                                                     (48, 6144, 4096, 8, 1, True)])
+def test_linear_tiled_w8(ops, dtype, M, N, K, tiles, groups, bias):
+    rng = rng_for("w8", dtype, M, N, K)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (N, K), dtype, 0.05)
+    b = grid(rng, (N,), dtype) if bias else None
+    q, scale = ops.tile_weights_fp8(dev(w, dtype))
+    q_ref, s_ref = R.quantize_rows_fp8(w)
+    ref = R.linear_w8(x, q_ref, s_ref, b, dtype)
+    ref64 = (x.astype(np.float64) @ q_ref.astype(np.float64).T) * s_ref[None, :].astype(np.float64)
+    if bias:
+        ref64 = ref64 + b.astype(np.float64)
+    tol = _linear_tol(ref64, x, q_ref * s_ref[:, None], K, dtype)
+    xd = dev(x, dtype)
+    if groups == 1:
+        y = host(ops.linear_tiled_w8(xd, q, scale, N, bias=dev(b, dtype) if bias else None, tiles_per_wg=tiles))
+        assert (np.abs(y - ref64) <= tol).all(), f"max err {np.abs(y - ref64).max()}"
+        assert (y != ref).mean() <= 0.02
+    part = ops.linear_tiled_w8(xd, q, scale, N, k_groups=groups, epilogue=ops.EPI_PARTIAL, tiles_per_wg=tiles).cpu().numpy()
+    y = _slab_sum(part, b, dtype)
+    assert (np.abs(y - ref64) <= tol).all(), f"max err {np.abs(y - ref64).max()}"
+    assert (y != ref).mean() <= 0.02
+    # the quantisation error itself, against the unquantised product, is what fp8 costs: a few percent of the scale
+    full = x.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
+    assert np.abs(y - full).max() <= 0.05 * np.abs(full).max() + 0.05
+
+
+@pytest.mark.parametrize("M,F,K", [(32, 14336, 4096), (64, 18944, 3584), (5, 512, 1024)])
+def test_linear_tiled_w8_swiglu(ops, M, F, K):
+    dtype = "bfloat16"
+    rng = rng_for("w8-silu", M, F, K)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (2 * F, K), dtype, 0.05)
+    xd = dev(x, dtype)
+    qi, si = ops.tile_weights_fp8(dev(w, dtype), interleave_halves=True)
+    y = host(ops.linear_tiled_w8(xd, qi, si, 2 * F, epilogue=ops.EPI_SILU_MUL))
+    q, s = ops.tile_weights_fp8(dev(w, dtype))
+    gu = ops.linear_tiled_w8(xd, q, s, 2 * F)
+    np.testing.assert_array_equal(y, host(ops.silu_and_mul(gu)))          # == the unfused HIP path
+    q_ref, s_ref = R.quantize_rows_fp8(w)
+    ref = R.silu_and_mul(R.linear_w8(x, q_ref, s_ref, None, dtype), dtype)
+    diff = np.abs(y - ref)
+    assert (diff <= 4 * ULP[dtype] * np.abs(ref) + 4 * ULP[dtype] * 1e-2).all()

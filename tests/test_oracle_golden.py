@@ -161,3 +161,22 @@ def test_tiny_model_bf16_close_to_hf(name):
     ref = g["tokens_bfloat16"]
     agree = (toks[:, :1] == ref[:, :1]).mean()
     assert agree >= 0.75
+
+
+def test_fp8_e4m3fn_rounding_matches_torch():
+    """The oracle's e4m3fn grid (decode table and round-to-nearest-even) against PyTorch's own
+    float8_e4m3fn conversion, an independent implementation available on the CPU."""
+    import torch
+    from oracle import ops_ref as R
+    table = R.fp8_e4m3fn_decode_table()
+    ref = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).float().numpy()
+    np.testing.assert_array_equal(np.nan_to_num(table, nan=777.0), np.nan_to_num(ref, nan=777.0))
+    rng = np.random.Generator(np.random.PCG64(5))
+    for scale in (150.0, 1.0, 0.01, 2.0 ** -8):
+        v = np.clip((rng.standard_normal(100000) * scale).astype(np.float32), -448, 448)
+        np.testing.assert_array_equal(R.fp8_e4m3fn_round(v), torch.from_numpy(v).to(torch.float8_e4m3fn).float().numpy())
+    ties = (np.arange(0, 448 * 16 + 1) / 16.0).astype(np.float32)     # many exact halfway cases
+    np.testing.assert_array_equal(R.fp8_e4m3fn_round(ties), torch.from_numpy(ties).to(torch.float8_e4m3fn).float().numpy())
+    q, s = R.quantize_rows_fp8(np.array([[0.0, 0.0], [1.0, -3.5], [448.0, 2.0]], np.float32))
+    np.testing.assert_array_equal(s, np.array([1.0, 3.5 / 448, 1.0], np.float32))
+    assert np.abs(q).max() == 448.0 and (q[0] == 0).all()

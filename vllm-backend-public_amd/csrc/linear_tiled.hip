@@ -57,9 +57,10 @@ struct FusedArgs {
   int64_t resid_stride;
   float* sumsq_out;          //   [gridDim.x][32]
   unsigned* counters;        // EPI_REDUCE_*: [gridDim.x], zero before the first launch, left zero
+  const float* w_scale;      // W8: [tiles * 16] fp32, one scale per weight row in tiled row order
 };
 
-template <typename T, int MT, int NW, int KSL, int EPI, bool NORM>
+template <typename T, int MT, int NW, int KSL, int EPI, bool NORM, bool W8 = false>
 __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
     uint16_t* __restrict__ y, float* __restrict__ partial, const uint16_t* __restrict__ x,
     const uint16_t* __restrict__ wt, const uint16_t* __restrict__ bias, int M, int N, int K,
@@ -132,33 +133,53 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   };
 
   // ---- weight stream of this wave: blocks [tile][kstep], 512 elements each
-  const uint16_t* wbase = wt + (static_cast<int64_t>(tile) * (K >> 5) + static_cast<int64_t>(p0) * (KSL / 32)) * 512 + lane * 8;
+  // W8: fp8 weights, 1 KB blocks of 16 rows x 64 k (a lane's 16 bytes are its 8 elements of two
+  // consecutive k-steps), so a group of U k-steps is U/2 loads and half the bytes
+  constexpr int LPG = W8 ? U / 2 : U;      // 1 KB loads per register group
+  const uint16_t* wbase = wt + ((static_cast<int64_t>(tile) * (K >> 5) + static_cast<int64_t>(p0) * (KSL / 32)) * 512 >> (W8 ? 1 : 0)) + lane * 8;
   const int groups_total = P * G;
-  auto load_group = [&](uint4 (&wd)[U], int g) {  // g clamped: the tail re-loads the last group (never used)
+  auto load_group = [&](uint4 (&wd)[LPG], int g) {  // g clamped: the tail re-loads the last group (never used)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const uint16_t* p = wbase + static_cast<int64_t>(min(g, groups_total - 1)) * (U * 512);
+    const uint16_t* p = wbase + static_cast<int64_t>(min(g, groups_total - 1)) * (LPG * 512);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < LPG; ++u) {
       const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + u * 512));
       wd[u] = make_uint4(v.x, v.y, v.z, v.w);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
+  // 8 fp8 (two dwords) -> the 8-element MFMA operand in the model's 16-bit type (exact: e4m3 fits both)
+  auto dequant8 = [&](uint32_t lo, uint32_t hi) {
+    float f[8];
+    const auto a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+    const auto c2 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d2 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+    f[0] = a[0]; f[1] = a[1]; f[2] = b[0]; f[3] = b[1];
+    f[4] = c2[0]; f[5] = c2[1]; f[6] = d2[0]; f[7] = d2[1];
+    return pack8<T>(f);
+  };
 
   f32x4 acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto compute = [&](uint4 (&wd)[U], int buf, int g) {  // g = group index inside the phase
+  auto compute = [&](uint4 (&wd)[LPG], int buf, int g) {  // g = group index inside the phase
     const unsigned char* xb = &lds[buf * XBUF + c * ROWB + g * (U * 64) + 16 * h];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int u = 0; u < U; ++u) {
+      uint4 a;
+      if (W8) {
+        const uint4 v = wd[u / 2];
+        a = (u & 1) ? dequant8(v.z, v.w) : dequant8(v.x, v.y);
+      } else {
+        a = wd[u];
+      }
 #pragma unroll
       for (int m = 0; m < MT; ++m)
-        acc[m] = T::mfma(wd[u], *reinterpret_cast<const uint4*>(xb + u * 64 + m * 16 * ROWB), acc[m]);
+        acc[m] = T::mfma(a, *reinterpret_cast<const uint4*>(xb + u * 64 + m * 16 * ROWB), acc[m]);
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  uint4 ring[D][U];
+  uint4 ring[D][LPG];
 #pragma unroll
   for (int j = 0; j < D - 1; ++j) load_group(ring[j], j);
   {
@@ -214,6 +235,16 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   // ---- epilogue: lane holds D[n = 4h + r][m = c] of each m-tile
   const int n0 = tile_raw * 16 + 4 * h;
   const bool live = tile_raw < tiles_total;
+  if (W8) {   // per-row weight scales, stored in tiled row order (so interleaved gate/up tiles find theirs)
+    const float4 sc = *reinterpret_cast<const float4*>(fa.w_scale + tile * 16 + 4 * h);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      acc[m][0] *= sc.x;
+      acc[m][1] *= sc.y;
+      acc[m][2] *= sc.z;
+      acc[m][3] *= sc.w;
+    }
+  }
   if (EPI == EPI_SILU_MUL) {
     __syncthreads();                                  // x buffers are dead: reuse them for the gate/up exchange
     float* ex = reinterpret_cast<float*>(lds);        // [pair][mt][r][lane]
@@ -382,14 +413,85 @@ __global__ void tile_weights_kernel(uint16_t* __restrict__ dst, const uint16_t* 
   }
 }
 
+// ---- fp8 (e4m3fn) weight copies: one fp32 scale per weight row, scale = max|row| / 448,
+// q = fp8_rne(w / scale).  Pass 1 writes the scales in TILED row order (what the GEMM
+// epilogue indexes); pass 2 tiles and quantises: block (tile, k-step pair) is 1 KB stored
+// as [lane][16 bytes], lane (i, h) holding row i's elements [64p + 8h, +8) and
+// [64p + 32 + 8h, +8) -- the lane's A operands of two consecutive k-steps.
+__device__ __forceinline__ int tiled_source_row(int tile, int i, int N, int interleave_halves) {
+  if (interleave_halves) {
+    const int pair = tile >> 1;
+    return pair * 16 + i < (N >> 1) ? (tile & 1) * (N >> 1) + pair * 16 + i : -1;
+  }
+  return tile * 16 + i < N ? tile * 16 + i : -1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_row_scale_kernel(float* __restrict__ scale_t, const uint16_t* __restrict__ src,
+                                                            int N, int K, int interleave_halves) {
+  const int tr = blockIdx.x;   // tiled row index
+  const int row = tiled_source_row(tr >> 4, tr & 15, N, interleave_halves);
+  float amax = 0.f;
+  if (row >= 0) {
+    const uint4* p = reinterpret_cast<const uint4*>(src + static_cast<int64_t>(row) * K);
+    for (int v = threadIdx.x; v < (K >> 3); v += 256) {
+      float f[8];
+      unpack8<T>(p[v], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    amax = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    scale_t[tr] = amax > 0.f ? amax / 448.0f : 1.0f;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void tile_weights_fp8_kernel(unsigned char* __restrict__ dst, const float* __restrict__ scale_t,
+                                                              const uint16_t* __restrict__ src, int N, int K,
+                                                              int tiles_total, int interleave_halves) {
+  const int64_t blocks = static_cast<int64_t>(tiles_total) * (K >> 6);
+  const int lane = threadIdx.x, i = lane & 15, h = lane >> 4;
+  for (int64_t b = blockIdx.x; b < blocks; b += gridDim.x) {
+    const int tile = static_cast<int>(b / (K >> 6)), kp = static_cast<int>(b % (K >> 6));
+    const int row = tiled_source_row(tile, i, N, interleave_halves);
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (row >= 0) {
+      const float sc = scale_t[tile * 16 + i];
+      const uint16_t* p = src + static_cast<int64_t>(row) * K + 64 * kp + 8 * h;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        float f[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(p + 32 * half), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = f[j] / sc;
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+        w[2 * half] = static_cast<uint32_t>(lo);
+        w[2 * half + 1] = static_cast<uint32_t>(hi);
+      }
+    }
+    *reinterpret_cast<uint4*>(dst + (b * 64 + lane) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
 #define MI355_LT_ARGS y, partial, x, wt, bias, M, N, K, xs, ys, tiles_total, phases
 #define MI355_LT_PARAMS                                                                                       \
   uint16_t *y, float *partial, const uint16_t *x, const uint16_t *wt, const uint16_t *bias, int M, int N, int K, \
       int64_t xs, int64_t ys, int tiles_total, int phases
 
-template <typename T, int MT, int NW, int KSL, int EPI, bool NORM>
+template <typename T, int MT, int NW, int KSL, int EPI, bool NORM, bool W8 = false>
 static void launch_one(dim3 grid, hipStream_t s, MI355_LT_PARAMS, const FusedArgs& fa) {
-  hipLaunchKernelGGL((linear_tiled_kernel<T, MT, NW, KSL, EPI, NORM>), grid, dim3(NW * 64), 0, s, MI355_LT_ARGS, fa);
+  hipLaunchKernelGGL((linear_tiled_kernel<T, MT, NW, KSL, EPI, NORM, W8>), grid, dim3(NW * 64), 0, s, MI355_LT_ARGS, fa);
 }
 
 // Which (epilogue, prologue) combinations exist for a geometry.  PLAIN: epilogues 0-2 on
@@ -397,6 +499,15 @@ static void launch_one(dim3 grid, hipStream_t s, MI355_LT_PARAMS, const FusedArg
 // for M <= 32 the norm prologue and the residual epilogue.
 template <typename T, int MT, int NW, int KSL, bool FUSED>
 static bool launch_cfg(int epi, bool norm, dim3 grid, hipStream_t s, MI355_LT_PARAMS, const FusedArgs& fa) {
+  if (fa.w_scale != nullptr) {   // fp8 weights: epilogues 0-2 on plain x, the decode step's geometries
+    if constexpr (FUSED) {
+      if (norm) return false;
+      if (epi == EPI_STORE) { launch_one<T, MT, NW, KSL, EPI_STORE, false, true>(grid, s, MI355_LT_ARGS, fa); return true; }
+      if (epi == EPI_SILU_MUL) { launch_one<T, MT, NW, KSL, EPI_SILU_MUL, false, true>(grid, s, MI355_LT_ARGS, fa); return true; }
+      if (epi == EPI_PARTIAL) { launch_one<T, MT, NW, KSL, EPI_PARTIAL, false, true>(grid, s, MI355_LT_ARGS, fa); return true; }
+    }
+    return false;
+  }
   if (!norm) {
     if (epi == EPI_STORE) { launch_one<T, MT, NW, KSL, EPI_STORE, false>(grid, s, MI355_LT_ARGS, fa); return true; }
     if (epi == EPI_SILU_MUL) { launch_one<T, MT, NW, KSL, EPI_SILU_MUL, false>(grid, s, MI355_LT_ARGS, fa); return true; }
@@ -456,6 +567,8 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
   const int ksl = (tiles_per_wg >= 100 ? 512 : 1024) / (mt <= 2 ? 1 : mt / 2);
   MI355_REQUIRE(N > 0 && K > 0 && K % ksl == 0, MI355_ERR_UNSUPPORTED,
                 "%s: K %d must be a multiple of the x slice %d (M %d)", name, K, ksl, M);
+  MI355_REQUIRE(fa.w_scale == nullptr || (aligned16(fa.w_scale) && epilogue <= EPI_PARTIAL), MI355_ERR_INVALID,
+                "%s: fp8 weights need a 16-byte aligned scale vector and epilogue 0-2", name);
   const int phases = K / ksl;
   const int pu = ksl >= 512 ? 1 : 2;   // 256-wide slices are walked two at a time
   MI355_REQUIRE(phases % pu == 0, MI355_ERR_UNSUPPORTED, "%s: K %d must be a multiple of %d for M %d", name, K,
@@ -506,8 +619,9 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
                       : launch_geometry<F16>(mt, nw, ksl, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K,
                                              x_stride, y_stride, tiles_total, phases, fa);
   MI355_REQUIRE(ok, MI355_ERR_UNSUPPORTED,
-                "%s: no kernel for M %d with tiles_per_wg %d, epilogue %d%s (M <= 32: 4/8/104/108, fused forms 8/104; "
-                "M <= 64: 8/104; M <= 128: 8)", name, M, tiles_per_wg, epilogue, norm ? " + norm prologue" : "");
+                "%s: no kernel for M %d with tiles_per_wg %d, epilogue %d%s (M <= 32: 4/8/104/108, fused and fp8 "
+                "forms 8/104; M <= 64: 8/104; M <= 128: 8)", name, M, tiles_per_wg, epilogue,
+                norm ? " + norm prologue" : "");
   return check_launch(name);
 }
 
@@ -557,5 +671,53 @@ extern "C" int32_t mi355_linear_tiled_fused(void* y, int64_t y_stride, float* pa
   const FusedArgs fa{static_cast<const uint16_t*>(norm_weight), norm_sumsq, norm_parts, eps,
                      static_cast<uint16_t*>(residual), residual_stride, sumsq_out, counters};
   return linear_tiled_launch("mi355_linear_tiled_fused", y, y_stride, partial, x, x_stride, w_tiled, bias, M, N, K,
+                             tiles_per_wg, k_groups, epilogue, fa, dtype, stream);
+}
+
+extern "C" int64_t mi355_tiled_weight_fp8_bytes(int32_t N, int32_t K) {
+  if (N <= 0 || K <= 0 || K % 64) return 0;
+  return static_cast<int64_t>((N + 15) / 16) * 16 * K;
+}
+
+extern "C" int32_t mi355_tile_weights_fp8(void* dst, float* scale_tiled, const void* src, int32_t N, int32_t K,
+                                          int32_t interleave_halves, int32_t dtype, void* stream) {
+  using namespace mi355;
+  const char* name = "mi355_tile_weights_fp8";
+  MI355_REQUIRE(dst && src && scale_tiled && dst != src, MI355_ERR_INVALID, "%s: null or aliased pointers", name);
+  MI355_REQUIRE(N > 0 && K > 0 && K % 64 == 0, MI355_ERR_UNSUPPORTED, "%s: K %d must be a multiple of 64", name, K);
+  MI355_REQUIRE(!interleave_halves || N % 32 == 0, MI355_ERR_UNSUPPORTED,
+                "%s: interleaving needs N %% 32 == 0 (two halves of whole 16-row tiles)", name);
+  MI355_REQUIRE(aligned16(dst) && aligned16(src) && aligned16(scale_tiled), MI355_ERR_INVALID,
+                "%s: pointers must be 16-byte aligned", name);
+  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED,
+                "%s: dtype %d not supported (bf16/fp16 only)", name, dtype);
+  const int tiles = (N + 15) / 16;
+  const int64_t blocks = static_cast<int64_t>(tiles) * (K / 64);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  auto* sp = static_cast<const uint16_t*>(src);
+  auto* dp = static_cast<unsigned char*>(dst);
+  const dim3 g1(tiles * 16), g2(static_cast<unsigned>(blocks > 65535 ? 65535 : blocks));
+  if (dtype == MI355_BF16) {
+    hipLaunchKernelGGL((fp8_row_scale_kernel<BF16>), g1, dim3(256), 0, s, scale_tiled, sp, N, K, interleave_halves);
+    hipLaunchKernelGGL((tile_weights_fp8_kernel<BF16>), g2, dim3(64), 0, s, dp, scale_tiled, sp, N, K, tiles, interleave_halves);
+  } else {
+    hipLaunchKernelGGL((fp8_row_scale_kernel<F16>), g1, dim3(256), 0, s, scale_tiled, sp, N, K, interleave_halves);
+    hipLaunchKernelGGL((tile_weights_fp8_kernel<F16>), g2, dim3(64), 0, s, dp, scale_tiled, sp, N, K, tiles, interleave_halves);
+  }
+  return check_launch(name);
+}
+
+extern "C" int32_t mi355_linear_tiled_w8(void* y, int64_t y_stride, void* partial, const void* x, int64_t x_stride,
+                                         const void* w_tiled_fp8, const float* w_scale, const void* bias, int32_t M,
+                                         int32_t N, int32_t K, int32_t tiles_per_wg, int32_t k_groups,
+                                         int32_t epilogue, int32_t dtype, void* stream) {
+  using namespace mi355;
+  const char* name = "mi355_linear_tiled_w8";
+  MI355_REQUIRE(w_scale != nullptr, MI355_ERR_INVALID, "%s: w_scale missing", name);
+  MI355_REQUIRE(epilogue == EPI_STORE || epilogue == EPI_SILU_MUL || epilogue == EPI_PARTIAL, MI355_ERR_INVALID,
+                "%s: unknown epilogue %d", name, epilogue);
+  FusedArgs fa{};
+  fa.w_scale = w_scale;
+  return linear_tiled_launch(name, y, y_stride, static_cast<float*>(partial), x, x_stride, w_tiled_fp8, bias, M, N, K,
                              tiles_per_wg, k_groups, epilogue, fa, dtype, stream);
 }

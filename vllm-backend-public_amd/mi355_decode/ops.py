@@ -483,3 +483,54 @@ def linear_tiled_fused(x: torch.Tensor, w_tiled: torch.Tensor, N: int, *, tiles_
     if epilogue == EPI_REDUCE_RESID:
         return residual
     return out
+
+
+def tile_weights_fp8(weight: torch.Tensor, interleave_halves: bool = False):
+    """Row-major 16-bit [N, K] -> (fp8 e4m3fn fragment-tiled bytes, fp32 row scales in tiled row order)."""
+    dt = _dt16(weight, "weight")
+    if weight.dim() != 2 or not weight.is_contiguous():
+        raise ValueError("weight must be contiguous [N, K]")
+    N, K = weight.shape
+    n = int(lib.mi355_tiled_weight_fp8_bytes(N, K))
+    if n == 0:
+        raise ValueError(f"K {K} must be a multiple of 64")
+    q = torch.empty(n, dtype=torch.uint8, device=weight.device)
+    scale = torch.empty((N + 15) // 16 * 16, dtype=torch.float32, device=weight.device)
+    check(lib.mi355_tile_weights_fp8(q.data_ptr(), scale.data_ptr(), weight.data_ptr(), N, K,
+                                     int(bool(interleave_halves)), dt, _stream()))
+    return q, scale
+
+
+def linear_tiled_w8(x: torch.Tensor, w_fp8: torch.Tensor, w_scale: torch.Tensor, N: int,
+                    bias: torch.Tensor | None = None, out: torch.Tensor | None = None,
+                    partial: torch.Tensor | None = None, tiles_per_wg: int = 0, k_groups: int = 1,
+                    epilogue: int = EPI_STORE):
+    """linear_tiled on fp8 weights from tile_weights_fp8 (x stays 16-bit; M <= 128)."""
+    dt = _dt16(x, "x")
+    _dev(w_fp8, "w_fp8"), _dev(w_scale, "w_scale")
+    M, K = x.shape
+    if w_fp8.dtype != torch.uint8 or w_fp8.numel() != int(lib.mi355_tiled_weight_fp8_bytes(N, K)):
+        raise ValueError("w_fp8 does not match (N, K)")
+    if w_scale.dtype != torch.float32 or w_scale.numel() != (N + 15) // 16 * 16 or not w_scale.is_contiguous():
+        raise ValueError("w_scale must be contiguous float32 [ceil(N/16)*16]")
+    if tiles_per_wg == 0:
+        tiles_per_wg = 8 if M > 64 or -(-((N + 15) // 16) // 8) * k_groups >= 160 else 104
+    y_ptr = p_ptr = y_stride = 0
+    if epilogue == EPI_PARTIAL:
+        if partial is None:
+            partial = torch.empty((k_groups, M, N), dtype=torch.float32, device=x.device)
+        _check_partial(partial, k_groups, M, N)
+        p_ptr, ret = partial.data_ptr(), partial
+    else:
+        width = N // 2 if epilogue == EPI_SILU_MUL else N
+        if out is None:
+            out = torch.empty((M, width), dtype=x.dtype, device=x.device)
+        elif out.dtype != x.dtype or tuple(out.shape) != (M, width):
+            raise ValueError(f"out must be [M, {width}] in the dtype of x")
+        y_ptr, y_stride, ret = out.data_ptr(), _rows(out, "out"), out
+    if bias is not None and (bias.dtype != x.dtype or bias.numel() != N or not bias.is_contiguous()):
+        raise ValueError("bias must be contiguous [N] in the dtype of x")
+    check(lib.mi355_linear_tiled_w8(y_ptr, y_stride, p_ptr, x.data_ptr(), _rows(x, "x"), w_fp8.data_ptr(),
+                                    w_scale.data_ptr(), bias.data_ptr() if bias is not None else 0, M, N, K,
+                                    tiles_per_wg, k_groups, epilogue, dt, _stream()))
+    return ret
