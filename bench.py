@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--prompt-len", type=int, default=128)
     ap.add_argument("--gen-len", type=int, default=128)
     ap.add_argument("--dtype", default="bfloat16")
+    ap.add_argument("--quantization", default=None, help="fp8: weight-only fp8 decode GEMMs (BASELINE.json configs[4])")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is marked invalid)")
     ap.add_argument("--decode-splits", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -59,7 +60,7 @@ def parse():
     return ap.parse_args()
 
 
-def model_bytes(cfg, tp, batch, mean_ctx, elem=2):
+def model_bytes(cfg, tp, batch, mean_ctx, elem=2, layer_w_elem=None):
     """Algorithmic HBM bytes of one decode step per GPU: every weight once
     (attention projections sharded over tp, MLP and lm_head replicated), the K/V
     pages of the mean context, the new K/V rows, and the logits."""
@@ -68,9 +69,11 @@ def model_bytes(cfg, tp, batch, mean_ctx, elem=2):
     attn_w = ((nh + 2 * nkv) * d * H + nh * d * H) // tp
     mlp_w = 3 * F * H
     norms = 2 * H
-    w = L * (attn_w + mlp_w + norms) + V * H + H
+    lw = elem if layer_w_elem is None else layer_w_elem      # fp8: 1 byte per layer weight + fp32 row scales
+    rows = ((nh + 2 * nkv) * d + H) // tp + 2 * F + H
+    w_bytes = L * ((attn_w + mlp_w) * lw + norms * elem + (rows * 4 if lw != elem else 0)) + (V * H + H) * elem
     kv_tok = 2 * (nkv // tp) * d * elem * L
-    return w * elem + batch * mean_ctx * kv_tok + batch * kv_tok + batch * V * elem, w * elem
+    return w_bytes + batch * mean_ctx * kv_tok + batch * kv_tok + batch * V * elem, w_bytes
 
 
 def make_prompts(vocab, batch, plen, seed):
@@ -119,7 +122,8 @@ def time_kernels(engine, batch, ctx_len):
     es = 2
     x, qkv, attn, o, gu, act, dn, resid = r.x[:b], r.qkv[:b], r.attn[:b], r.o[:b], r.gu[:b], r.act[:b], r.dn[:b], r.resid[:b]
     W = r.w.layers
-    gemm = lambda m, n, k, out_es=es: n * k * es + m * k * es + m * n * out_es   # noqa: E731
+    wes = 1 if r.weight_fp8 else es                      # bytes per layer-weight element
+    gemm = lambda m, n, k, out_es=es, w_es=None: n * k * (wes if w_es is None else w_es) + m * k * es + m * n * out_es   # noqa: E731
     tiled = r._use_tiled(b)
     if tiled:
         T, P = r.tiled, ops.EPI_PARTIAL
@@ -129,16 +133,17 @@ def time_kernels(engine, batch, ctx_len):
         out["impl"] = ("hand-written weight-streaming GEMMs on fragment-tiled weights (linear_tiled_kernel); "
                        f"geometry qkv {tq}/{gq}, o {to}/{go}, gate_up {tg}/1 + SwiGLU epilogue, down {td}/{gd}"
                        + ("" if "o" in plans else "; o projection: hipBLASLt (16-bit output for the all-reduce)"))
-        out["gemm_gate_up"] = timed(lambda i: ops.linear_tiled(x, T[i]["gu"], 2 * r.F, out=act, tiles_per_wg=tg,
-                                                               epilogue=ops.EPI_SILU_MUL),
-                                    2 * r.F * r.H * es + b * r.H * es + b * r.F * es)
-        out["gemm_down"] = timed(lambda i: ops.linear_tiled(act, T[i]["down"], r.H, partial=r.part_dn, tiles_per_wg=td,
-                                                            k_groups=gd, epilogue=P), gemm(b, r.H, r.F, 4 * gd))
-        out["gemm_qkv"] = timed(lambda i: ops.linear_tiled(x, T[i]["qkv"], r.qw, partial=r.part_qkv, tiles_per_wg=tq,
-                                                           k_groups=gq, epilogue=P), gemm(b, r.qw, r.H, 4 * gq))
+        lt = r._linear_tiled
+        out["gemm_gate_up"] = timed(lambda i: lt(x, T[i]["gu"], 2 * r.F, out=act, tiles_per_wg=tg,
+                                                 epilogue=ops.EPI_SILU_MUL),
+                                    2 * r.F * r.H * wes + b * r.H * es + b * r.F * es)
+        out["gemm_down"] = timed(lambda i: lt(act, T[i]["down"], r.H, partial=r.part_dn, tiles_per_wg=td,
+                                              k_groups=gd, epilogue=P), gemm(b, r.H, r.F, 4 * gd))
+        out["gemm_qkv"] = timed(lambda i: lt(x, T[i]["qkv"], r.qw, partial=r.part_qkv, tiles_per_wg=tq,
+                                             k_groups=gq, epilogue=P), gemm(b, r.qw, r.H, 4 * gq))
         if "o" in plans:
-            out["gemm_o"] = timed(lambda i: ops.linear_tiled(attn, T[i]["o"], r.H, partial=r.part_o, tiles_per_wg=to,
-                                                             k_groups=go, epilogue=P), gemm(b, r.H, r.nh * r.d, 4 * go))
+            out["gemm_o"] = timed(lambda i: lt(attn, T[i]["o"], r.H, partial=r.part_o, tiles_per_wg=to,
+                                               k_groups=go, epilogue=P), gemm(b, r.H, r.nh * r.d, 4 * go))
         else:
             out["gemm_o"] = timed(lambda i: torch.mm(attn, W[i].o_w.t(), out=o), gemm(b, r.H, r.nh * r.d))
     else:
@@ -148,7 +153,7 @@ def time_kernels(engine, batch, ctx_len):
         out["gemm_qkv"] = timed(lambda i: torch.mm(x, W[i].qkv_w.t(), out=qkv), gemm(b, r.qw, r.H))
         out["gemm_o"] = timed(lambda i: torch.mm(attn, W[i].o_w.t(), out=o), gemm(b, r.H, r.nh * r.d))
     lm = r.w.lm_head
-    out["gemm_lm_head"] = timed(lambda i: r.lm_head_logits(x, r.logits[:b]), gemm(b, r.V, r.H))
+    out["gemm_lm_head"] = timed(lambda i: r.lm_head_logits(x, r.logits[:b]), gemm(b, r.V, r.H, w_es=es))
 
     # attention over the live cache, at the context lengths of the last timed step
     splits = r._splits_for(b)
@@ -278,7 +283,8 @@ def main():
     cfg = ModelConfig.from_pretrained(a.model)
     args = EngineArgs(model=a.model, dtype=a.dtype, max_num_seqs=batch, max_model_len=P + G,
                       max_num_batched_tokens=max(8192, 1), tensor_parallel_size=tp, load_format="dummy",
-                      gpu_memory_utilization=0.9, enforce_eager=a.eager, num_layers_override=a.layers, seed=0)
+                      gpu_memory_utilization=0.9, enforce_eager=a.eager, num_layers_override=a.layers, seed=0,
+                      quantization=a.quantization)
     engine = build_engine(args, model_config=cfg, decode_splits=a.decode_splits)
     params = SamplingParams(max_tokens=G, temperature=0.0, ignore_eos=True)
 
@@ -341,18 +347,20 @@ def main():
     ms_per_step = total_t / a.steps * 1e3
     tok_s = batch * a.steps / total_t
 
-    step_bytes, w_bytes = model_bytes(cfg, tp, batch, mean_ctx)
+    lwe = 1 if a.quantization == "fp8" else None
+    step_bytes, w_bytes = model_bytes(cfg, tp, batch, mean_ctx, layer_w_elem=lwe)
     if a.layers:
         import copy
         c2 = copy.copy(cfg)
         c2.num_hidden_layers = a.layers
-        step_bytes, w_bytes = model_bytes(c2, tp, batch, mean_ctx)
+        step_bytes, w_bytes = model_bytes(c2, tp, batch, mean_ctx, layer_w_elem=lwe)
     step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
 
     result = {
         "metric": "decode_tok_s", "value": round(tok_s, 1), "unit": "tok/s", "n_gpus": a.gpus, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16" if a.dtype == "bfloat16" else a.dtype, "data": "synthetic",
+        "vs_baseline": None, "dtype": ("bf16" if a.dtype == "bfloat16" else a.dtype) + ("+fp8w" if lwe else ""),
+        "data": "synthetic",
         "config": {"workload": f"{a.model} decode, batch {batch} ({a.batch_per_gpu}/GPU), {P}-in/{G}-out, greedy, "
                                f"synthetic weights and token-id prompts; BASELINE.json configs[{1 if a.gpus == 1 else 2}]",
                    "global_batch": batch, "prompt_len": P, "gen_len": G,

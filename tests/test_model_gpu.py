@@ -324,3 +324,31 @@ def test_tensor_parallel_rank_step_tiled_vs_library(batch, monkeypatch):
     err = np.abs(logits[True] - logits[False])
     assert np.isfinite(logits[True]).all()
     assert err.max() <= LOGIT_TOL[dtype] * scale and err.mean() <= LOGIT_MEAN_TOL[dtype] * scale
+
+
+@pytest.mark.parametrize("name", ["llama_d128", "qwen2_d128"])
+def test_fp8_weights_engine_matches_oracle_on_the_quantised_model(name):
+    """--quantization fp8: the engine (fp8 weight stream at decode, dequantised 16-bit copies at
+    prefill) against the oracle run on the same quantised model, w' = fp8(w / scale) * scale per
+    weight row with scale = max|row| / 448."""
+    arch, cfg, w = make_weights(name)
+    w = {k: R.round_to(v, "bfloat16") for k, v in w.items()}
+    wq = {}
+    for k, v in w.items():
+        if v.ndim == 2 and "proj" in k:
+            q, s = R.quantize_rows_fp8(v)
+            wq[k] = (q * s[:, None]).astype(np.float32)
+        else:
+            wq[k] = v
+    prompts = make_prompts(name, len(LENGTHS), LENGTHS)
+    eng, _, _ = build(name, "bfloat16", quantization="fp8")
+    assert eng.runner.weight_fp8 and isinstance(eng.runner.tiled[0]["qkv"], tuple), "fp8 weight stream not active"
+    ref_tokens, ref_logits = oracle_run(cfg, wq, "bfloat16", prompts, 16)
+    scale = np.abs(ref_logits[0]).max()
+    got = engine_generate(eng, prompts, 16)
+    exact = compare_tokens(got, ref_tokens, ref_logits, LOGIT_TOL["bfloat16"] * scale * 2)
+    print(f"{name} fp8: {exact}/{ref_tokens.size} tokens identical to the oracle before the first near-tie")
+    assert exact >= 0.5 * ref_tokens.size
+    # and the quantised model is a different model: its logits differ from the unquantised oracle's
+    _, full_logits = oracle_run(cfg, w, "bfloat16", prompts, 1)
+    assert np.abs(full_logits[0] - ref_logits[0]).max() > 4 * 2.0 ** -8 * scale

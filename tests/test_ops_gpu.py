@@ -724,8 +724,8 @@ def test_linear_tiled_rejects_unbuilt_geometries(ops):
     wt = ops.tile_weights(torch.zeros(64, 1024, dtype=torch.bfloat16, device="cuda"))
     with pytest.raises(Mi355Error, match="no kernel for M 128"):
         ops.linear_tiled(x, wt, 64, tiles_per_wg=4)
-    with pytest.raises(Mi355Error, match="multiple of 512"):
-        ops.linear_tiled(x[:, :768].contiguous(), ops.tile_weights(torch.zeros(64, 768, dtype=torch.bfloat16, device="cuda")),
+    with pytest.raises(Mi355Error, match="multiple of the x slice"):
+        ops.linear_tiled(x[:, :640].contiguous(), ops.tile_weights(torch.zeros(64, 640, dtype=torch.bfloat16, device="cuda")),
                          64, tiles_per_wg=8)
     with pytest.raises(Mi355Error, match="outside"):
         ops.linear_tiled(torch.zeros(129, 1024, dtype=torch.bfloat16, device="cuda"), wt, 64)
@@ -799,9 +799,9 @@ def _k_ranges(K, unit, groups):
     return out
 
 
-@pytest.mark.parametrize("M,N,K,tiles,groups,unit", [(32, 3584, 3584, 104, 3, 512), (64, 3584, 18944, 104, 4, 512),
-                                                     (16, 512, 7168, 8, 3, 1024), (128, 1024, 18944, 8, 5, 512),
-                                                     (20, 256, 2560, 104, 5, 512)])
+@pytest.mark.parametrize("M,N,K,tiles,groups,unit", [(32, 3584, 3584, 104, 3, 512), (64, 3584, 18944, 104, 4, 256),
+                                                     (16, 512, 7168, 8, 3, 1024), (128, 1024, 18944, 8, 5, 256),
+                                                     (20, 256, 2560, 104, 5, 512), (100, 512, 768, 8, 2, 256)])
 def test_linear_tiled_uneven_k_split(ops, M, N, K, tiles, groups, unit):
     """K / slice is not a multiple of the group count (Qwen2-7B: 3584 = 7 x 512, 18944 = 37 x 512)."""
     dtype = "bfloat16"
@@ -899,3 +899,23 @@ def test_linear_tiled_w8_swiglu(ops, M, F, K):
     ref = R.silu_and_mul(R.linear_w8(x, q_ref, s_ref, None, dtype), dtype)
     diff = np.abs(y - ref)
     assert (diff <= 4 * ULP[dtype] * np.abs(ref) + 4 * ULP[dtype] * 1e-2).all()
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_linear_tiled_w8_decodes_every_fp8_code_exactly(ops, dtype):
+    """Weights whose quantised codes run over the whole e4m3fn table (subnormals and both zeros
+    included), read back through one-hot inputs: the in-register fp8 -> 16-bit conversion is exact."""
+    table = R.fp8_e4m3fn_decode_table()
+    codes = np.array([c for c in range(256) if np.isfinite(table[c])])
+    K, N = 512, 64
+    w = np.zeros((N, K), np.float32)
+    for n in range(N):
+        w[n] = table[np.roll(np.resize(codes, K), 7 * n)]
+        w[n, (3 * n) % K] = 448.0                                  # row scale exactly 1
+    q, scale = ops.tile_weights_fp8(dev(w, dtype))
+    np.testing.assert_array_equal(scale.cpu().numpy()[:N], np.ones(N, np.float32))
+    for k0 in range(0, K, 32):
+        x = np.zeros((32, K), np.float32)
+        x[np.arange(32), k0 + np.arange(32)] = 1.0
+        y = host(ops.linear_tiled_w8(dev(x, dtype), q, scale, N, tiles_per_wg=104))
+        np.testing.assert_array_equal(y, w[:, k0:k0 + 32].T)

@@ -28,6 +28,13 @@ struct BF16 {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
                                                    __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
+  // two fp8 (e4m3fn) of the low / high half of `src` -> two packed 16-bit values (exact)
+  static __device__ __forceinline__ uint32_t fp8x2(uint32_t src, bool high_half) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 v2;
+    const v2 r = high_half ? __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(src, 1.0f, true)
+                           : __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(src, 1.0f, false);
+    return __builtin_bit_cast(uint32_t, r);
+  }
 };
 
 struct F16 {
@@ -41,6 +48,12 @@ struct F16 {
   static __device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
                                                   __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t fp8x2(uint32_t src, bool high_half) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+    const v2 r = high_half ? __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(src, 1.0f, true)
+                           : __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(src, 1.0f, false);
+    return __builtin_bit_cast(uint32_t, r);
   }
 };
 

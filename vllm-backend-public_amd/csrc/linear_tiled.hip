@@ -71,11 +71,11 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   constexpr int ROWB = KSL * 2 + 32;       // padded LDS row (bytes)
   constexpr int XBUF = ROWS * ROWB;
   constexpr int G = KSL / 32 / U;          // register groups per phase (8, 4 or 2)
-  constexpr int D = 4;                     // ring depth
+  constexpr int D = W8 ? 8 : 4;            // ring depth: fp8 groups are half the bytes, so twice as many are in flight
   constexpr int PU = G >= D ? 1 : D / G;   // phases per main-loop iteration: ring slots stay compile-time
-  const int units = phases_total / PU, ubase = units / static_cast<int>(gridDim.y), urem = units % static_cast<int>(gridDim.y);
-  const int P = (ubase + (static_cast<int>(blockIdx.y) < urem ? 1 : 0)) * PU;
-  const int p0 = (static_cast<int>(blockIdx.y) * ubase + min(static_cast<int>(blockIdx.y), urem)) * PU;
+  const int ubase = phases_total / static_cast<int>(gridDim.y), urem = phases_total % static_cast<int>(gridDim.y);
+  const int P = ubase + (static_cast<int>(blockIdx.y) < urem ? 1 : 0);
+  const int p0 = static_cast<int>(blockIdx.y) * ubase + min(static_cast<int>(blockIdx.y), urem);
   static_assert((PU * G) % D == 0, "ring slots must repeat every main-loop iteration");
   static_assert(!NORM || MT <= 2, "the norm prologue is built for M <= 32");
   static_assert(EPI != EPI_REDUCE_RESID || MT <= 2, "the sum-of-squares table has 32 rows");
@@ -90,9 +90,8 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   const int tile_raw = blockIdx.x * NW + wave;
   const int tile = min(tile_raw, tiles_total - 1);
   const int kgroup = blockIdx.y;
-  // K range of this workgroup: the slices are dealt to the K groups in units of PU (the
-  // main loop's stride), the first `rem` groups taking one unit more -- any group count up to
-  // the unit count works, K need not divide evenly
+  // K range of this workgroup: the slices are dealt to the K groups as evenly as they go, the
+  // first `rem` groups taking one more -- any group count up to the slice count works
 
   // ---- x slice staging: 16-byte vectors, whole rows, coalesced
   constexpr int NX = ROWS * (KSL / 8) / NT;
@@ -148,14 +147,10 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  // 8 fp8 (two dwords) -> the 8-element MFMA operand in the model's 16-bit type (exact: e4m3 fits both)
+  // 8 fp8 (two dwords) -> the 8-element MFMA operand in the model's 16-bit type: four
+  // v_cvt_scalef32_pk_*_fp8 with scale 1 (exact: every e4m3 value fits both 16-bit types)
   auto dequant8 = [&](uint32_t lo, uint32_t hi) {
-    float f[8];
-    const auto a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
-    const auto c2 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d2 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
-    f[0] = a[0]; f[1] = a[1]; f[2] = b[0]; f[3] = b[1];
-    f[4] = c2[0]; f[5] = c2[1]; f[6] = d2[0]; f[7] = d2[1];
-    return pack8<T>(f);
+    return make_uint4(T::fp8x2(lo, false), T::fp8x2(lo, true), T::fp8x2(hi, false), T::fp8x2(hi, true));
   };
 
   f32x4 acc[MT];
@@ -213,10 +208,11 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
     x_commit(xs0, 0);
   }
   __syncthreads();
-  for (int p = 0; p < P; p += PU) {        // P % PU == 0 (checked on the host)
+  for (int p = 0; p < P; p += PU) {        // every iteration starts at ring slot 0 ((PU * G) % D == 0)
 #pragma unroll
     for (int pp = 0; pp < PU; ++pp) {
       const int q = p + pp;
+      if (q >= P) break;                     // P need not be a multiple of PU
       const bool more = q + 1 < P;
       xvec xs[NXA];                          // lives inside one phase only
       x_issue(xs, p0 + (more ? q + 1 : q));  // unconditional (the last phase re-loads its own slice, unused)
@@ -570,11 +566,8 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
   MI355_REQUIRE(fa.w_scale == nullptr || (aligned16(fa.w_scale) && epilogue <= EPI_PARTIAL), MI355_ERR_INVALID,
                 "%s: fp8 weights need a 16-byte aligned scale vector and epilogue 0-2", name);
   const int phases = K / ksl;
-  const int pu = ksl >= 512 ? 1 : 2;   // 256-wide slices are walked two at a time
-  MI355_REQUIRE(phases % pu == 0, MI355_ERR_UNSUPPORTED, "%s: K %d must be a multiple of %d for M %d", name, K,
-                ksl * pu, M);
-  MI355_REQUIRE(k_groups >= 1 && k_groups <= phases / pu, MI355_ERR_INVALID,
-                "%s: k_groups %d outside [1, %d] (K / %d)", name, k_groups, phases / pu, ksl * pu);
+  MI355_REQUIRE(k_groups >= 1 && k_groups <= phases, MI355_ERR_INVALID, "%s: k_groups %d outside [1, %d] (K / %d)",
+                name, k_groups, phases, ksl);
   MI355_REQUIRE(k_groups == 1 || epilogue == EPI_PARTIAL || reduce, MI355_ERR_INVALID,
                 "%s: k_groups > 1 needs a partial-sum or reducing epilogue", name);
   MI355_REQUIRE(x_stride >= K && x_stride % 8 == 0 && aligned16(x) && aligned16(w_tiled), MI355_ERR_INVALID,

@@ -88,14 +88,15 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
     tp = kw["tp_size"]
     # the runner keeps a second, fragment-tiled copy of the decode-time matrices (the o
     # projection only without tensor parallelism)
-    tiled_bytes = sum(t.numel() * t.element_size() for lw in weights.layers
+    fp8 = (args.quantization or "").lower() == "fp8"
+    tiled_bytes = sum(t.numel() * (1 if fp8 else t.element_size()) for lw in weights.layers
                       for t in (lw.qkv_w, lw.gate_up_w, lw.down_w) + ((lw.o_w,) if tp == 1 else ()))
     tiled_bytes += weights.lm_head.numel() * weights.lm_head.element_size()
     num_blocks = plan_num_blocks(args, cfg, tp, len(weights.layers), max_model_len,
                                  torch.empty(0, dtype=dtype).element_size(), device, extra_reserve=tiled_bytes)
     runner = ModelRunner(cfg, weights, dtype, device, num_blocks, args.max_num_seqs, max_model_len,
                          tp_rank=rank, tp_size=tp, tp_group=group, use_graphs=not args.enforce_eager,
-                         decode_splits=decode_splits)
+                         decode_splits=decode_splits, weight_fp8=(args.quantization or "").lower() == "fp8")
     eos = cfg.eos_token_id
     eos = [] if eos is None else (list(eos) if isinstance(eos, (list, tuple)) else [eos])
     return LLMEngine(runner, args.max_num_seqs, max(args.max_num_batched_tokens, 1), max_model_len, eos,

@@ -58,7 +58,8 @@ class ModelRunner:
     def __init__(self, cfg: ModelConfig, weights: ModelWeights, dtype: torch.dtype, device,
                  num_blocks: int, max_num_seqs: int, max_model_len: int, tp_rank: int = 0,
                  tp_size: int = 1, tp_group=None, use_graphs: bool = True,
-                 decode_splits: Optional[int] = None, tiled_linears: Optional[bool] = None):
+                 decode_splits: Optional[int] = None, tiled_linears: Optional[bool] = None,
+                 weight_fp8: bool = False):
         self.cfg, self.w, self.dtype, self.device = cfg, weights, dtype, torch.device(device)
         self.tp_rank, self.tp_size, self.tp_group = tp_rank, tp_size, tp_group
         self.nh = cfg.num_attention_heads // tp_size
@@ -75,6 +76,7 @@ class ModelRunner:
         self.max_blocks = (self.max_model_len + BLOCK_SIZE - 1) // BLOCK_SIZE
         self.use_graphs = use_graphs
         self.decode_splits = decode_splits
+        self.weight_fp8 = bool(weight_fp8)
 
         dev = self.device
         self.cos_sin = build_cos_sin_table(cfg, self.max_model_len, dtype, dev)
@@ -115,6 +117,8 @@ class ModelRunner:
         self.graphs = {}
         self.buckets = batch_buckets(B)
         self._init_tiled(tiled_linears)
+        if self.weight_fp8:
+            self._fake_quantize_row_major()
         # pinned host staging for the packed inputs and the sampled tokens: two sets, so
         # that the host can stage step n+1 while step n is still running
         self.h64s = [torch.zeros(3 * B, dtype=torch.int64).pin_memory() for _ in range(self.NUM_STAGES)]
@@ -150,11 +154,12 @@ class ModelRunner:
         if self.tiled_max_m == 0:
             return
         self.tiled = []
+        # fp8: (bytes, row scales) per matrix instead of a 16-bit tiled tensor; the lm_head stays 16-bit
+        tile = ops.tile_weights_fp8 if self.weight_fp8 else ops.tile_weights
         for lw in self.w.layers:
-            tw = {"qkv": ops.tile_weights(lw.qkv_w), "gu": ops.tile_weights(lw.gate_up_w, interleave_halves=True),
-                  "down": ops.tile_weights(lw.down_w)}
+            tw = {"qkv": tile(lw.qkv_w), "gu": tile(lw.gate_up_w, interleave_halves=True), "down": tile(lw.down_w)}
             if self.tp_size == 1:
-                tw["o"] = ops.tile_weights(lw.o_w)
+                tw["o"] = tile(lw.o_w)
             self.tiled.append(tw)
         self.lm_head_tiled = ops.tile_weights(self.w.lm_head)
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -167,6 +172,25 @@ class ModelRunner:
         self.part_qkv = torch.empty(size["qkv"], **f32)
         self.part_o = torch.empty(max(size["o"], 4), **f32)
         self.part_dn = torch.empty(size["down"], **f32)
+
+    def _fake_quantize_row_major(self) -> None:
+        """--quantization fp8: the row-major matrices (prefill, large batches, the TP o projection) are
+        replaced by what the fp8 copies decode to -- round(fp8(w / scale) * scale), scale = max|row| / 448
+        -- so that every path computes with the same quantised model."""
+        def fq(w: torch.Tensor) -> None:
+            f = w.float()
+            amax = f.abs().amax(dim=1, keepdim=True)
+            scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+            w.copy_(((f / scale).to(torch.float8_e4m3fn).float() * scale).to(w.dtype))
+        for lw in self.w.layers:
+            for t in (lw.qkv_w, lw.o_w, lw.gate_up_w, lw.down_w):
+                fq(t)
+
+    def _linear_tiled(self, x, w, N, **kw):
+        """linear_tiled on a tiled weight of this runner (16-bit tensor, or (fp8 bytes, scales))."""
+        if isinstance(w, tuple):
+            return ops.linear_tiled_w8(x, w[0], w[1], N, **kw)
+        return ops.linear_tiled(x, w, N, **kw)
 
     def _tiled_plan(self, m: int):
         """{layer: (tiles_per_wg, k_groups)} for m rows, or None if some layer has no kernel."""
@@ -190,21 +214,21 @@ class ModelRunner:
                 ops.rms_norm(resid, lw.input_norm, self.eps, out=x)
             else:
                 ops.fused_add_rms_norm_partial(self.part_dn, gd, resid, lw.input_norm, self.eps, x)
-            ops.linear_tiled(x, tw["qkv"], self.qw, partial=self.part_qkv, tiles_per_wg=tq, k_groups=gq, epilogue=P)
+            self._linear_tiled(x, tw["qkv"], self.qw, partial=self.part_qkv, tiles_per_wg=tq, k_groups=gq, epilogue=P)
             ops.paged_attn_decode_fused(None, self.cos_sin, slots, self.k_cache[i], self.v_cache[i], bt, ctx,
                                         self.nh, self.nkv, self.d, self.scale, num_splits=splits,
                                         workspace=self.attn_ws, out=attn, partial=self.part_qkv, num_slabs=gq,
                                         bias=lw.qkv_b)
             if self.tp_size == 1:
                 to, go = plans["o"]
-                ops.linear_tiled(attn, tw["o"], self.H, partial=self.part_o, tiles_per_wg=to, k_groups=go, epilogue=P)
+                self._linear_tiled(attn, tw["o"], self.H, partial=self.part_o, tiles_per_wg=to, k_groups=go, epilogue=P)
                 ops.fused_add_rms_norm_partial(self.part_o, go, resid, lw.post_norm, self.eps, x)
             else:
                 torch.mm(attn, lw.o_w.t(), out=o)
                 self._allreduce(o)
                 ops.fused_add_rms_norm(o, resid, lw.post_norm, self.eps, out=x)
-            ops.linear_tiled(x, tw["gu"], 2 * self.F, out=act, tiles_per_wg=tg, epilogue=ops.EPI_SILU_MUL)
-            ops.linear_tiled(act, tw["down"], self.H, partial=self.part_dn, tiles_per_wg=td, k_groups=gd, epilogue=P)
+            self._linear_tiled(x, tw["gu"], 2 * self.F, out=act, tiles_per_wg=tg, epilogue=ops.EPI_SILU_MUL)
+            self._linear_tiled(act, tw["down"], self.H, partial=self.part_dn, tiles_per_wg=td, k_groups=gd, epilogue=P)
         ops.fused_add_rms_norm_partial(self.part_dn, gd, resid, self.w.final_norm, self.eps, x)
 
     def lm_head_logits(self, x: torch.Tensor, out: torch.Tensor) -> None:

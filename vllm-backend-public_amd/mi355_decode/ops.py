@@ -360,10 +360,9 @@ def plan_linear_tiled(N: int, K: int, split_k: bool, M: int = 32):
         candidates = [104]
     for tiles in candidates:
         ksl = tiled_slice_width(M, tiles)
-        unit = ksl if ksl >= 512 else 2 * ksl          # 256-wide slices are walked two at a time
-        if K % unit:
+        if K % ksl:
             continue
-        units = K // unit
+        units = K // ksl
         wgs = -(-tiles_total // (tiles % 100))
         groups = 1
         if split_k and wgs < 160:
