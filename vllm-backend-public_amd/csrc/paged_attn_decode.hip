@@ -151,7 +151,7 @@ __device__ __forceinline__ void rotate8(const float (&x1)[8], const float (&x2)[
   }
 }
 
-template <typename T, int D, int FUSE, int SLABS>
+template <typename T, int D, int FUSE, int SLABS, bool SPLIT>
 __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
     uint16_t* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_ml,
     const uint16_t* __restrict__ q, int64_t q_stride, uint16_t* k_cache,
@@ -167,6 +167,17 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, h = lane >> 4;
 
+  // Without splits the block-table entries of a wave's first step do not depend on the context
+  // length: their (vector) loads go out before the (scalar) context-length load, so the two
+  // round trips overlap instead of the scalar wait holding the vector loads back.
+  const int32_t* bt = block_tables + static_cast<int64_t>(seq) * max_blocks;
+  int e0 = 0, e1 = 0;
+  if (!SPLIT) {   // compile-time: a run-time branch around the loads would drain them at its join
+    const int bi = min(2 * wave, max_blocks - 1);
+    e0 = bt[bi];
+    e1 = bt[min(bi + 1, max_blocks - 1)];
+  }
+  __builtin_amdgcn_sched_barrier(0);
   int ctx = context_lens[seq];
   const int ctx_cap = max_blocks * BS;
   ctx = ctx < 0 ? 0 : (ctx > ctx_cap ? ctx_cap : ctx);
@@ -176,7 +187,6 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
   const int t_begin = split * per_split;
   const int t_end = min(ctx, t_begin + per_split);
 
-  const int32_t* bt = block_tables + static_cast<int64_t>(seq) * max_blocks;
   const int last_blk_idx = ctx > 0 ? (ctx - 1) / BS : 0;
   const int koff = ((c >> 2) & 1) * 8 + (c & 3);  // token row inside the page for tile "a"
 
@@ -207,12 +217,9 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
   // The loads of the wave's first step are in flight while the query is prepared.  They are
   // unconditional (a wave without tokens loads a valid page it never uses): a load inside a
   // branch makes the compiler drain the load queue at the join, which would put the page loads
-  // and the query's loads one after the other.  Without splits the first step's block-table
-  // entries do not depend on the context length, so their load starts together with the
-  // context-length load instead of after it: one dependent memory round trip less.
-  if (num_splits == 1) {
-    const int bi = min(2 * wave, max_blocks - 1);
-    issue_page_loads(bt[bi], bt[min(bi + 1, max_blocks - 1)]);
+  // and the query's loads one after the other.
+  if (!SPLIT) {
+    issue_page_loads(e0, e1);
   } else {
     issue_loads(tb);
   }
@@ -469,11 +476,16 @@ static int32_t launch_decode(void* out, const void* q, int64_t q_stride, void* k
     part_ml = part_o + static_cast<int64_t>(num_seqs) * num_heads * num_splits * D;
   }
   dim3 grid(num_seqs, num_kv_heads, num_splits), block(kDecodeThreads);
-  hipLaunchKernelGGL((paged_attn_decode_kernel<T, D, FUSE, SLABS>), grid, block, 0, s, static_cast<uint16_t*>(out),
-                     part_o, part_ml, static_cast<const uint16_t*>(q), q_stride,
-                     static_cast<uint16_t*>(k_cache), static_cast<uint16_t*>(v_cache),
-                     num_blocks, block_tables, max_blocks, context_lens, num_heads, num_kv_heads,
-                     scale * 1.4426950408889634f, num_splits, ra);
+  if (num_splits == 1)
+    hipLaunchKernelGGL((paged_attn_decode_kernel<T, D, FUSE, SLABS, false>), grid, block, 0, s,
+                       static_cast<uint16_t*>(out), part_o, part_ml, static_cast<const uint16_t*>(q), q_stride,
+                       static_cast<uint16_t*>(k_cache), static_cast<uint16_t*>(v_cache), num_blocks, block_tables,
+                       max_blocks, context_lens, num_heads, num_kv_heads, scale * 1.4426950408889634f, num_splits, ra);
+  else
+    hipLaunchKernelGGL((paged_attn_decode_kernel<T, D, FUSE, SLABS, true>), grid, block, 0, s,
+                       static_cast<uint16_t*>(out), part_o, part_ml, static_cast<const uint16_t*>(q), q_stride,
+                       static_cast<uint16_t*>(k_cache), static_cast<uint16_t*>(v_cache), num_blocks, block_tables,
+                       max_blocks, context_lens, num_heads, num_kv_heads, scale * 1.4426950408889634f, num_splits, ra);
   int32_t rc = check_launch("mi355_paged_attn_decode");
   if (rc != MI355_OK || num_splits == 1) return rc;
   hipLaunchKernelGGL((paged_attn_merge_kernel<T, D>), dim3(num_seqs * num_heads), dim3(D), 0, s,
