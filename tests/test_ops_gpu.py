@@ -917,3 +917,17 @@ def test_linear_tiled_w8_decodes_every_fp8_code_exactly(ops, dtype):
         x[np.arange(32), k0 + np.arange(32)] = 1.0
         y = host(ops.linear_tiled_w8(dev(x, dtype), q, scale, N, tiles_per_wg=104))
         np.testing.assert_array_equal(y, w[:, k0:k0 + 32].T)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,F,K", [(128, 14336, 4096), (64, 2048, 1024)])
+def test_linear_tiled_w8_swiglu_fused_equals_unfused_at_more_rows(ops, dtype, M, F, K):
+    """fp16 is where a folded conversion shows: the scaled accumulator and silu(g) must be rounded
+    from their fp32 values in the fused epilogue exactly as in the store epilogue + SwiGLU kernel."""
+    rng = rng_for("w8-silu-rows", dtype, M, F, K)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (2 * F, K), dtype, 0.05)
+    xd = dev(x, dtype)
+    q, s = ops.tile_weights_fp8(dev(w, dtype))
+    qi, si = ops.tile_weights_fp8(dev(w, dtype), interleave_halves=True)
+    y = host(ops.linear_tiled_w8(xd, qi, si, 2 * F, epilogue=ops.EPI_SILU_MUL))
+    np.testing.assert_array_equal(y, host(ops.silu_and_mul(ops.linear_tiled_w8(xd, q, s, 2 * F))))

@@ -62,6 +62,28 @@ __device__ __forceinline__ float round_f(float f) {
   return T::to_f(T::from_f(f));
 }
 
+// An fp32 value that is about to be rounded to 16 bits, pinned as an fp32 register value: without
+// this the backend may fold the conversion into the instruction that produces the value (a
+// mixed-precision fma rounds the exact result once, not to fp32 first) in one kernel and not in
+// another, and the two disagree where the fp32 value is a tie on the 16-bit grid.
+__device__ __forceinline__ float pin_f32(float v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// SwiGLU gate on values already on the 16-bit grid: round(silu(g)) * u (the caller rounds the
+// product).  One definition for every kernel; contraction off and the quotient pinned, so that
+// the "1 +" is not fused with the last multiply inside the inlined expf and the rounding of
+// silu(g) is not folded into the last step of the division.
+template <typename T>
+__device__ __forceinline__ float silu_mul(float g, float u) {
+#pragma clang fp contract(off)
+  const float e = expf(-g);
+  const float d = 1.0f + e;
+  const float s = round_f<T>(pin_f32(g / d));
+  return s * u;
+}
+
 // 8 packed 16-bit words <-> 8 floats
 template <typename T>
 __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {

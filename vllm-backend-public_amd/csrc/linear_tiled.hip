@@ -235,10 +235,10 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
     const float4 sc = *reinterpret_cast<const float4*>(fa.w_scale + tile * 16 + 4 * h);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      acc[m][0] *= sc.x;
-      acc[m][1] *= sc.y;
-      acc[m][2] *= sc.z;
-      acc[m][3] *= sc.w;
+      acc[m][0] = pin_f32(acc[m][0] * sc.x);   // an fp32 value of its own before any 16-bit rounding
+      acc[m][1] = pin_f32(acc[m][1] * sc.y);
+      acc[m][2] = pin_f32(acc[m][2] * sc.z);
+      acc[m][3] = pin_f32(acc[m][3] * sc.w);
     }
   }
   if (EPI == EPI_SILU_MUL) {
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
       for (int r = 0; r < 4; ++r) {
         const float g = round_f<T>(acc[m][r]);
         const float u = round_f<T>(ex[(((wave >> 1) * MT + m) * 4 + r) * 64 + lane]);
-        o[r] = round_f<T>(g / (1.0f + expf(-g))) * u;
+        o[r] = silu_mul<T>(g, u);
       }
       uint16_t* yp = y + static_cast<int64_t>(mm) * y_stride + j0;
       if (j0 + 3 < F) {

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void silu_and_mul_kernel(uint16_t* __restrict_
     unpack8<T>(*reinterpret_cast<const uint4*>(xr + 8 * v), g);
     unpack8<T>(*reinterpret_cast<const uint4*>(xr + inter + 8 * v), u);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) y[j] = round_f<T>(g[j] / (1.0f + expf(-g[j]))) * u[j];
+    for (int j = 0; j < 8; ++j) y[j] = silu_mul<T>(g[j], u[j]);
     *reinterpret_cast<uint4*>(out + row * inter + 8 * v) = pack8<T>(y);
   }
 }
