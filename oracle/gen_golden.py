@@ -314,6 +314,30 @@ def gen_harness():
     print("harness_results.json:", {k: v["accepted"] for k, v in res["cases"].items()})
 
 
+def gen_plugin():
+    """Outputs of the reference's own VLLMProcessor (benchmark-mlflow/vllm_processor.py) on sample chart
+    values: what a sibling processor has to reproduce for the sections both fill."""
+    import copy
+    sys.path.insert(0, os.path.join(REF, "benchmark-mlflow"))
+    from vllm_processor import VLLMProcessor
+    proc = VLLMProcessor("http://benchmark-eval:8004/evaluate")
+    base = {"global": {"keep": "me"},
+            "vllm": {"vllm": {"model": "x", "dtype": "bfloat16", "max_num_seqs": 32}, "fullnameOverride": "x",
+                     "serviceAccount": {"create": True, "name": "x"},
+                     "resources": {"limits": {"nvidia.com/gpu": 1, "memory": "64Gi"}, "requests": {"nvidia.com/gpu": 1}}}}
+    cases = {}
+    for name in ("meta-llama/Meta-Llama-3-8B", "Qwen/Qwen2-7B", "org/My_Model.v2"):
+        out = proc.process_yaml_data(copy.deepcopy(base), name, "run-1", "exp-7", "model-3", "2")
+        out["global"].pop("timestamp")
+        cases[name] = {"values": out, "application": proc.get_application_name(name)}
+    nov = proc.process_yaml_data({"other": 1}, "a/b", "r", "e", "m", "1")
+    nov["global"].pop("timestamp")
+    with open(os.path.join(GOLD, "harness_plugin.json"), "w") as f:
+        json.dump({"base": base, "eval_url": "http://benchmark-eval:8004/evaluate", "cases": cases,
+                   "no_vllm_section": nov}, f, indent=1, sort_keys=True)
+    print("harness_plugin.json:", list(cases))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["ops", "tiny", "harness"]
@@ -326,3 +350,5 @@ if __name__ == "__main__":
         gen_tiny(only)
     if "harness" in which:
         gen_harness()
+    if "plugin" in which or not sys.argv[1:]:
+        gen_plugin()

@@ -137,3 +137,35 @@ def test_bench_client_payload_is_ingestible():
     assert set(p) == set(RESULTS["cases"]["full"]["payload"])
     assert result_pk(p) == HR.stored_document(p)["pk"]
     json.dumps(p)                                         # wire format
+
+
+def test_engine_plugin_processor_matches_the_reference_vllm_processor():
+    """Mi355Processor fills every key the reference's VLLMProcessor fills with the same values
+    (golden: the reference's own processor run on sample chart values), and differs only where
+    it must: the image and the GPU resource key."""
+    import copy
+    import json
+    import os
+    from mi355_decode.harness_plugin import GPU_RESOURCE, Mi355Processor
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", "harness_plugin.json")) as f:
+        g = json.load(f)
+    proc = Mi355Processor(g["eval_url"], gpus=1)
+    for name, case in g["cases"].items():
+        out = proc.process_yaml_data(copy.deepcopy(g["base"]), name, "run-1", "exp-7", "model-3", "2")
+        assert len(out["global"].pop("timestamp")) == 15
+        ref = case["values"]
+        assert out["global"] == ref["global"]
+        assert proc.get_application_name(name) == case["application"]
+        mine, theirs = out["vllm"], ref["vllm"]
+        for key in ("vllm", "fullnameOverride", "serviceAccount"):
+            assert mine[key] == theirs[key], key
+        assert mine["image"]["repository"].endswith("mi355-decode")
+        for kind in ("limits", "requests"):
+            assert "nvidia.com/gpu" not in mine["resources"][kind] and mine["resources"][kind][GPU_RESOURCE] == 1
+        assert mine["resources"]["limits"]["memory"] == "64Gi"            # everything else is left alone
+    nov = proc.process_yaml_data({"other": 1}, "a/b", "r", "e", "m", "1")
+    nov["global"].pop("timestamp")
+    assert nov == g["no_vllm_section"]
+    tp = Mi355Processor(g["eval_url"], gpus=4).process_yaml_data(copy.deepcopy(g["base"]), "a/b", "r", "e", "m", "1")
+    assert tp["vllm"]["vllm"]["tensor_parallel_size"] == 4 and tp["vllm"]["resources"]["limits"][GPU_RESOURCE] == 4
