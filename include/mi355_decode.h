@@ -233,6 +233,19 @@ int32_t mi355_sample_topk_topp(int64_t* out_ids, const void* logits,
                                const int64_t* steps, void* stream);
 
 /*
+ * Log-probabilities for the `logprobs` field of POST /v1/completions
+ * (benchmark-deployer/docs/deployment/post_run.md:46):
+ *   out_lse[b]     = log(sum_v exp(logits[b, v]))            (fp32, fixed-order sum)
+ *   out_logprob[b] = logits[b, token_ids[b]] - out_lse[b]    (-inf for an id outside the vocabulary)
+ * Either output may be NULL.  Any other logit of the row becomes a log-probability
+ * by subtracting out_lse[b].  logits may be bf16, fp16 or fp32; row stride in elements.
+ */
+int32_t mi355_token_logprobs(float* out_logprob, float* out_lse, const void* logits,
+                             int64_t logits_stride, int32_t num_rows, int32_t vocab,
+                             int32_t logits_dtype, const int64_t* token_ids,
+                             void* stream);
+
+/*
  * Decode-time linear layer  y[M, N] = x[M, K] . W[N, K]^T (+ bias[N]),  M <= 128:
  * the weight matrix is streamed from HBM exactly once (fp32 accumulation on the
  * matrix cores, one rounding of the result).  W row-major [N, K] contiguous;

@@ -64,7 +64,8 @@ class FakeRunner:
         assert (toks >= 0).all(), "read a slot that was never written"
         return toks.tolist()
 
-    def launch_decode(self, n, stage=0, sampling=None, ids_from_device=False):
+    def launch_decode(self, n, stage=0, sampling=None, ids_from_device=False, logprobs=-1):
+        self.logprobs_k = logprobs
         """Computes at once (the double has no queue) but hands the result over only in finish_decode."""
         self.last_sampling = sampling
         self.sampling_log.append(sampling)
@@ -87,13 +88,15 @@ class FakeRunner:
         self.dev_next = list(out)
         self.results[stage] = out
 
-    def finish_decode(self, n, stage=0):
+    def finish_decode(self, n, stage=0, logprobs=-1):
         out, self.results[stage] = self.results[stage], None
         assert out is not None and len(out) == n
+        if logprobs >= 0:                     # fake log-probabilities: -token/1000, top-k = token, token+1, ...
+            return out, [(-t / 1000.0, [(t + j, -(t + j) / 1000.0) for j in range(logprobs)]) for t in out]
         return out
 
     def run_prefill(self, token_ids, positions, slot_mapping, block_tables, cu_seqlens, context_lens, max_q_len,
-                    sampling=None):
+                    sampling=None, logprobs=-1):
         self.last_sampling = sampling
         assert len(token_ids) == len(positions) == len(slot_mapping) == cu_seqlens[-1]
         self.cache[slot_mapping] = token_ids
@@ -106,6 +109,8 @@ class FakeRunner:
                                           np.arange(context_lens[i] - qlen, context_lens[i]))
             out.append(next_token(self._context(block_tables[i], int(context_lens[i]))))
         self.prefill_tokens.append(int(cu_seqlens[-1]))
+        if logprobs >= 0:
+            return out, [(-t / 1000.0, [(t + j, -(t + j) / 1000.0) for j in range(logprobs)]) for t in out]
         return out
 
 
@@ -327,3 +332,25 @@ def test_abort_while_a_step_is_in_flight():
     got = run(eng)
     assert early + got["b"] == reference(list(range(12)), 10)
     assert "a" not in got and eng.alloc.num_free == eng.alloc.num_blocks
+
+
+def test_logprobs_follow_each_request_own_width():
+    """A step computes the widest top-k any of its requests asked for; every request gets its own width
+    (and none at all if it did not ask), for the prefill token and for tokens of steps launched ahead."""
+    eng, runner = make_engine()
+    eng.add_request("a", [1, 2, 3], SamplingParams(max_tokens=4, temperature=0.0, logprobs=3))
+    eng.add_request("b", [4, 5], SamplingParams(max_tokens=4, temperature=0.0, logprobs=0))
+    eng.add_request("c", [6], SamplingParams(max_tokens=4, temperature=0.0))
+    seen = {"a": [], "b": [], "c": []}
+    toks = {"a": [], "b": [], "c": []}
+    while eng.has_unfinished():
+        for o in eng.step():
+            toks[o.request_id] += o.new_token_ids
+            seen[o.request_id].append(o.logprobs)
+    assert runner.logprobs_k == 3
+    assert all(x is None for x in seen["c"])
+    for lp, t in zip(seen["a"], toks["a"]):
+        assert lp == [(-t / 1000.0, [(t + j, -(t + j) / 1000.0) for j in range(3)])]
+    for lp, t in zip(seen["b"], toks["b"]):
+        assert lp == [(-t / 1000.0, [])]
+    assert len(seen["a"]) == 4 and toks["a"] == reference([1, 2, 3], 4)

@@ -352,3 +352,38 @@ def test_fp8_weights_engine_matches_oracle_on_the_quantised_model(name):
     # and the quantised model is a different model: its logits differ from the unquantised oracle's
     _, full_logits = oracle_run(cfg, w, "bfloat16", prompts, 1)
     assert np.abs(full_logits[0] - ref_logits[0]).max() > 4 * 2.0 ** -8 * scale
+
+
+def test_logprobs_through_the_engine_match_the_oracle():
+    """`logprobs=k`: the engine's per-token log-probabilities and top-k lists against the log-softmax
+    of the oracle's logits for the same tokens (prefill token and decode tokens, run-ahead on)."""
+    from mi355_decode.sampling_params import SamplingParams
+    name, gen, k = "llama_d128", 8, 3
+    eng, cfg, w = build(name, "bfloat16")
+    prompts = make_prompts(name, len(LENGTHS), LENGTHS)
+    ref_tokens, ref_logits = oracle_run(cfg, w, "bfloat16", prompts, gen)
+    toks = {i: [] for i in range(len(prompts))}
+    lps = {i: [] for i in range(len(prompts))}
+    for i, p in enumerate(prompts):
+        eng.add_request(str(i), [int(t) for t in p],
+                        SamplingParams(max_tokens=gen, temperature=0.0, ignore_eos=True, logprobs=k if i % 2 == 0 else None))
+    while eng.has_unfinished():
+        for o in eng.step():
+            toks[int(o.request_id)] += o.new_token_ids
+            if o.logprobs is not None:
+                lps[int(o.request_id)] += o.logprobs
+    scale = np.abs(ref_logits[0]).max()
+    for i in range(len(prompts)):
+        if i % 2:
+            assert lps[i] == []
+            continue
+        assert len(lps[i]) == gen
+        for t in range(gen):
+            if toks[i][t] != ref_tokens[i, t]:
+                break                                      # left the oracle's sequence at a near-tie: stop comparing
+            lp, top = lps[i][t]
+            row = R.round_to(ref_logits[t][i], "bfloat16")[None]
+            want, _ = R.token_logprobs(row, [toks[i][t]])
+            assert abs(lp - want[0]) <= LOGIT_TOL["bfloat16"] * scale * 2, (i, t, lp, want[0])
+            assert len(top) == k and top[0][0] == toks[i][t] and abs(top[0][1] - lp) < 1e-6   # greedy: chosen = most likely
+            assert all(top[j][1] >= top[j + 1][1] for j in range(k - 1)) and lp <= 0

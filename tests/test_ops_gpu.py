@@ -931,3 +931,22 @@ def test_linear_tiled_w8_swiglu_fused_equals_unfused_at_more_rows(ops, dtype, M,
     qi, si = ops.tile_weights_fp8(dev(w, dtype), interleave_halves=True)
     y = host(ops.linear_tiled_w8(xd, qi, si, 2 * F, epilogue=ops.EPI_SILU_MUL))
     np.testing.assert_array_equal(y, host(ops.silu_and_mul(ops.linear_tiled_w8(xd, q, s, 2 * F))))
+
+
+@pytest.mark.parametrize("ldt", ["float32", "bfloat16", "float16"])
+@pytest.mark.parametrize("B,V", [(1, 8), (7, 1000), (32, 128256), (3, 152064)])
+def test_token_logprobs(ops, ldt, B, V):
+    rng = rng_for("logprob", ldt, B, V)
+    logits = (rng.standard_normal((B, V)) * 3).astype(np.float32)
+    logits[0, V // 2] = 30.0                                   # a dominant token: logprob ~ 0
+    if ldt != "float32":
+        logits = R.round_to(logits, ldt)
+    ids = rng.integers(0, V, B).astype(np.int64)
+    ids[0] = V // 2
+    t = torch.from_numpy(logits).to({"float32": torch.float32, **DT}[ldt]).cuda()
+    lp, lse = ops.token_logprobs(t, torch.from_numpy(ids).cuda())
+    lp_ref, lse_ref = R.token_logprobs(logits, ids)
+    np.testing.assert_allclose(lse.cpu().numpy(), lse_ref, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(lp.cpu().numpy(), lp_ref, rtol=1e-5, atol=5e-6)
+    lp2, _ = ops.token_logprobs(t, torch.from_numpy(ids).cuda())
+    np.testing.assert_array_equal(lp.cpu().numpy(), lp2.cpu().numpy())      # fixed-order sums: same bits every launch

@@ -118,7 +118,7 @@ def test_errors_are_openai_style_json():
                        ({"prompt": [1], "n": 2}, 400), ({"prompt": [V + 5]}, 400), ({"prompt": []}, 400),
                        ({"prompt": list(range(600))}, 400), ({"prompt": [1], "max_tokens": 0}, 400),
                        ({"prompt": [1], "temperature": -1}, 400), ({"prompt": [1], "top_p": 0}, 400),
-                       ({"prompt": [1], "logprobs": 5}, 400)]:
+                       ({"prompt": [1], "logprobs": 50}, 400), ({"prompt": [1], "logprobs": 2, "echo": True}, 400)]:
         r = c.post("/v1/completions", json=body)
         assert r.status_code == code, (body, r.text)
         err = r.json()["error"]
@@ -172,3 +172,25 @@ def test_prompt_normalisation_and_detokenizer():
     ids = tok.encode("héllo")                               # multi-byte char split over two tokens
     out = "".join(d.push([i]) for i in ids)
     assert out == "héllo"
+
+
+def test_logprobs_object_of_a_completion():
+    """`logprobs: k`: OpenAI text-completion logprobs object, one entry per generated token,
+    top_logprobs of width k; streamed chunks carry the step's entries."""
+    th, c, _, tok = make()
+    th.ready.wait(10)
+    r = c.post("/v1/completions", json={"prompt": [5, 6, 7], "max_tokens": 5, "temperature": 0, "logprobs": 2})
+    assert r.status_code == 200, r.text
+    lp = r.json()["choices"][0]["logprobs"]
+    assert set(lp) == {"tokens", "token_logprobs", "top_logprobs", "text_offset"}
+    assert len(lp["tokens"]) == len(lp["token_logprobs"]) == len(lp["top_logprobs"]) == len(lp["text_offset"]) == 5
+    assert all(v <= 0 for v in lp["token_logprobs"]) and all(len(t) <= 2 for t in lp["top_logprobs"])
+    assert lp["text_offset"] == sorted(lp["text_offset"]) and lp["text_offset"][0] == 0
+    r0 = c.post("/v1/completions", json={"prompt": [5, 6, 7], "max_tokens": 3, "temperature": 0, "logprobs": 0})
+    assert r0.json()["choices"][0]["logprobs"]["top_logprobs"] == [None, None, None]
+    with c.stream("POST", "/v1/completions", json={"prompt": [5, 6, 7], "max_tokens": 4, "temperature": 0, "logprobs": 1,
+                                                   "stream": True}) as resp:
+        chunks = [json.loads(line[6:]) for line in resp.iter_lines() if line.startswith("data: {")]
+    got = [t for ch in chunks if ch["choices"][0]["logprobs"] for t in ch["choices"][0]["logprobs"]["token_logprobs"]]
+    assert len(got) == 4
+    th.shutdown()

@@ -51,6 +51,7 @@ def _load() -> ctypes.CDLL:
         "mi355_tiled_weight_elems": (I64, [I32, I32]),
         "mi355_tile_weights": (I32, [P, P, I32, I32, I32, P]),
         "mi355_linear_tiled": (I32, [P, I64, P, P, I64, P, P, I32, I32, I32, I32, I32, I32, I32, P]),
+        "mi355_token_logprobs": (I32, [P, P, P, I64, I32, I32, I32, P, P]),
         "mi355_tiled_weight_fp8_bytes": (I64, [I32, I32]),
         "mi355_tile_weights_fp8": (I32, [P, P, P, I32, I32, I32, I32, P]),
         "mi355_linear_tiled_w8": (I32, [P, I64, P, P, I64, P, P, P, I32, I32, I32, I32, I32, I32, I32, P]),
@@ -81,7 +82,8 @@ EXPORTS = ("mi355_abi_version", "mi355_last_error", "mi355_target_arch", "mi355_
            "mi355_tiled_weight_elems", "mi355_tile_weights", "mi355_linear_tiled",
            "mi355_fused_add_rms_norm_partial", "mi355_rope_kv_write_partial",
            "mi355_linear_tiled_fused", "mi355_paged_attn_decode_fused",
-           "mi355_tiled_weight_fp8_bytes", "mi355_tile_weights_fp8", "mi355_linear_tiled_w8")
+           "mi355_tiled_weight_fp8_bytes", "mi355_tile_weights_fp8", "mi355_linear_tiled_w8",
+           "mi355_token_logprobs")
 
 
 def check(status: int) -> None:

@@ -96,6 +96,9 @@ class RequestOutput:
     arrival_time: float
     first_token_time: Optional[float]
     finish_time: Optional[float]
+    # one entry per new token when the request asked for logprobs: (logprob of the token,
+    # [(token id, logprob)] of the most likely tokens, most likely first)
+    logprobs: Optional[list] = None
 
 
 class Scheduler:
@@ -285,9 +288,19 @@ class LLMEngine:
             "steps": np.asarray([len(s.output_ids) + s.inflight for s in seqs], dtype=np.int64),
         }
 
-    def _output(self, seq: Sequence, new: List[int]) -> RequestOutput:
+    def _output(self, seq: Sequence, new: List[int], lp=None) -> RequestOutput:
+        k = seq.params.logprobs
+        if lp is not None and k is not None:
+            lp = [(lp[0], lp[1][:k])]
+        else:
+            lp = None
         return RequestOutput(seq.request_id, new, seq.finished, seq.finish_reason, len(seq.prompt_ids),
-                             len(seq.output_ids), seq.arrival_time, seq.first_token_time, seq.finish_time)
+                             len(seq.output_ids), seq.arrival_time, seq.first_token_time, seq.finish_time, lp)
+
+    @staticmethod
+    def _logprobs_k(seqs: List[Sequence]) -> int:
+        """Top-k width a step has to compute: the largest any of its requests asked for; -1: none did."""
+        return max([s.params.logprobs for s in seqs if s.params.logprobs is not None], default=-1)
 
     def _prefill(self, chunks) -> List[RequestOutput]:
         MB = self.runner.max_blocks
@@ -303,10 +316,13 @@ class LLMEngine:
             cu.append(cu[-1] + n)
             ctx.append(start + n)
             bt[i, : len(seq.blocks)] = seq.blocks
+        k = self._logprobs_k([c[0] for c in chunks])
+        kw = {"logprobs": k} if k >= 0 else {}
         nxt = self.runner.run_prefill(np.concatenate(toks), np.concatenate(pos), np.concatenate(slots), bt,
                                       np.asarray(cu, dtype=np.int32), np.asarray(ctx, dtype=np.int32),
                                       max(n for _, _, n in chunks),
-                                      sampling=self._sampling_arrays([c[0] for c in chunks]))
+                                      sampling=self._sampling_arrays([c[0] for c in chunks]), **kw)
+        nxt, lps = nxt if k >= 0 else (nxt, None)
         now = time.perf_counter()
         outs = []
         self.stats["prefill_steps"] += 1
@@ -315,7 +331,7 @@ class LLMEngine:
             self.stats["prefill_tokens"] += n
             if seq.num_computed >= seq.total_len:        # prompt complete: this step sampled a token
                 self._append_token(seq, int(nxt[i]), now)
-                outs.append(self._output(seq, [seq.output_ids[-1]]))
+                outs.append(self._output(seq, [seq.output_ids[-1]], lps[i] if lps else None))
         return outs
 
     # ------------------------------------------------------------------ #
@@ -343,10 +359,12 @@ class LLMEngine:
             n64[2 * B + i] = seq.blocks[p // BLOCK_SIZE] * BLOCK_SIZE + p % BLOCK_SIZE
             n32[i] = p + 1
             bt[i, : len(seq.blocks)] = seq.blocks
-        r.launch_decode(n, st, sampling=self._sampling_arrays(seqs), ids_from_device=ahead)
+        k = self._logprobs_k(seqs)
+        kw = {"logprobs": k} if k >= 0 else {}
+        r.launch_decode(n, st, sampling=self._sampling_arrays(seqs), ids_from_device=ahead, **kw)
         for seq in seqs:
             seq.inflight += 1
-        self._pending.append((seqs, st))
+        self._pending.append((seqs, st, k))
 
     def _try_launch_ahead(self, seqs: List[Sequence]) -> None:
         """Launch the step after the one in flight if its batch is certain to be the
@@ -367,19 +385,22 @@ class LLMEngine:
         self._launch_decode(seqs, ahead=True)
 
     def _harvest_decode(self) -> List[RequestOutput]:
-        seqs, st = self._pending.popleft()
-        toks = self.runner.finish_decode(len(seqs), st)
+        seqs, st, k = self._pending.popleft()
+        if k >= 0:
+            toks, lps = self.runner.finish_decode(len(seqs), st, logprobs=k)
+        else:
+            toks, lps = self.runner.finish_decode(len(seqs), st), None
         now = time.perf_counter()
         self.stats["decode_steps"] += 1
         outs = []
-        for seq, tok in zip(seqs, toks):
+        for i, (seq, tok) in enumerate(zip(seqs, toks)):
             seq.inflight -= 1
             if not seq.blocks:                # finished, aborted or preempted while the step was in flight
                 continue
             self.stats["decode_tokens"] += 1
             seq.num_computed = seq.total_len
             self._append_token(seq, int(tok), now)
-            outs.append(self._output(seq, [seq.output_ids[-1]]))
+            outs.append(self._output(seq, [seq.output_ids[-1]], lps[i] if lps else None))
         return outs
 
     def step(self) -> List[RequestOutput]:

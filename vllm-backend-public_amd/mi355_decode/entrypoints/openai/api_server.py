@@ -124,8 +124,10 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
             prompts = normalise_prompts(body["prompt"], tokenizer, vocab_size)
             if body.get("n", 1) != 1 or body.get("best_of", 1) not in (None, 1):
                 raise ValueError("n > 1 / best_of > 1 are not supported")
-            if body.get("logprobs") not in (None, 0, False):
-                raise ValueError("logprobs is not supported yet")
+            want_lp = body.get("logprobs")
+            want_lp = None if want_lp is None or want_lp is False else int(want_lp)
+            if want_lp is not None and body.get("echo"):
+                raise ValueError("logprobs together with echo (prompt log-probabilities) is not supported")
             stop = body.get("stop") or []
             params = SamplingParams(
                 max_tokens=int(body.get("max_tokens", 16) if body.get("max_tokens") is not None else 16),
@@ -135,7 +137,7 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
                 top_k=int(body.get("top_k", -1) if body.get("top_k") is not None else -1),
                 seed=body.get("seed"), stop=[stop] if isinstance(stop, str) else list(stop),
                 stop_token_ids=list(body.get("stop_token_ids") or []),
-                ignore_eos=bool(body.get("ignore_eos", False)))
+                ignore_eos=bool(body.get("ignore_eos", False)), logprobs=want_lp)
             for p in prompts:
                 if len(p) + 1 > max_model_len:
                     raise ValueError(f"This model's maximum context length is {max_model_len} tokens; the prompt has "
@@ -160,6 +162,23 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
         texts = [tokenizer.decode(p) if echo else "" for p in prompts]
         n_out = [0] * len(prompts)
         reasons: List[Optional[str]] = [None] * len(prompts)
+        # OpenAI text-completion logprobs object per choice, filled token by token
+        lp_objs = [{"tokens": [], "token_logprobs": [], "top_logprobs": [], "text_offset": []} if want_lp is not None
+                   else None for _ in prompts]
+
+        def add_logprobs(i: int, o, offset: int) -> Optional[dict]:
+            """Appends the step's tokens to choice i's logprobs object; returns the same fields for this step alone."""
+            if lp_objs[i] is None or not o.logprobs:
+                return None
+            step = {"tokens": [], "token_logprobs": [], "top_logprobs": [], "text_offset": []}
+            for tok, (lp, top) in zip(o.new_token_ids, o.logprobs):
+                step["tokens"].append(tokenizer.decode([tok]))
+                step["token_logprobs"].append(lp)
+                step["top_logprobs"].append({tokenizer.decode([t]): v for t, v in top} if want_lp else None)
+                step["text_offset"].append(offset)
+            for k2, v in step.items():
+                lp_objs[i][k2].extend(v)
+            return step
 
         def apply_stop(i: int) -> bool:
             """Cut text at the first stop string; True if one was hit."""
@@ -180,6 +199,7 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
                 if reasons[i] is not None:
                     continue
                 n_out[i] = o.num_output_tokens
+                step_lp = add_logprobs(i, o, len(texts[i]))
                 texts[i] += detoks[i].push(o.new_token_ids, final=o.finished)
                 hit = bool(params.stop) and apply_stop(i)
                 if hit:
@@ -191,7 +211,7 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
                     done += 1
                 delta = texts[i][sent[i]:]
                 sent[i] = len(texts[i])
-                yield i, delta, reasons[i]
+                yield i, delta, reasons[i], step_lp
 
         usage = lambda: {"prompt_tokens": sum(len(p) for p in prompts), "completion_tokens": sum(n_out),  # noqa: E731
                          "total_tokens": sum(len(p) for p in prompts) + sum(n_out)}
@@ -199,11 +219,11 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
         if stream:
             async def sse():
                 try:
-                    async for i, delta, reason in events():
-                        if delta or reason is not None:
+                    async for i, delta, reason, step_lp in events():
+                        if delta or reason is not None or step_lp is not None:
                             chunk = {"id": cmpl_id, "object": "text_completion", "created": int(time.time()),
                                      "model": served_model_name,
-                                     "choices": [{"index": i, "text": delta, "logprobs": None, "finish_reason": reason}]}
+                                     "choices": [{"index": i, "text": delta, "logprobs": step_lp, "finish_reason": reason}]}
                             yield f"data: {json.dumps(chunk)}\n\n"
                     yield "data: [DONE]\n\n"
                 except asyncio.CancelledError:
@@ -226,7 +246,7 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
             return _error(500, f"engine error: {exc!r}", "internal_error")
         return JSONResponse({"id": cmpl_id, "object": "text_completion", "created": int(time.time()),
                              "model": served_model_name,
-                             "choices": [{"index": i, "text": texts[i], "logprobs": None, "finish_reason": reasons[i]}
+                             "choices": [{"index": i, "text": texts[i], "logprobs": lp_objs[i], "finish_reason": reasons[i]}
                                          for i in range(len(prompts))],
                              "usage": usage()})
 

@@ -54,6 +54,7 @@ def batch_buckets(max_num_seqs: int):
 
 class ModelRunner:
     NUM_STAGES = 2
+    MAX_LOGPROBS = 20
 
     def __init__(self, cfg: ModelConfig, weights: ModelWeights, dtype: torch.dtype, device,
                  num_blocks: int, max_num_seqs: int, max_model_len: int, tp_rank: int = 0,
@@ -126,6 +127,9 @@ class ModelRunner:
                      for _ in range(self.NUM_STAGES)]
         self.h_nexts = [torch.zeros(B, dtype=torch.int64).pin_memory() for _ in range(self.NUM_STAGES)]
         self.done = [torch.cuda.Event() for _ in range(self.NUM_STAGES)]
+        # log-probabilities of a step (only when a request asked for them): chosen token, top-k ids / values
+        self.h_lp = [torch.zeros(B, 1 + 2 * self.MAX_LOGPROBS, dtype=torch.float32).pin_memory()
+                     for _ in range(self.NUM_STAGES)]
         self.h64, self.h32, self.h_next = self.h64s[0], self.h32s[0], self.h_nexts[0]
 
     # ------------------------------------------------------------------ #
@@ -359,8 +363,24 @@ class ModelRunner:
                    t(sampling["top_p"], torch.float32), t(sampling["seeds"], torch.int64),
                    t(sampling["steps"], torch.int64), out=out)
 
+    def _logprobs(self, logits: torch.Tensor, chosen: torch.Tensor, k: int) -> torch.Tensor:
+        """[rows, 1 + 2k] float32 on the device: log-probability of the chosen token, then the k
+        most likely token ids (as floats: exact below 2^24) and their log-probabilities.  The
+        log-sum-exp is the HIP kernel's; picking the top k is a selection, not arithmetic."""
+        lp, lse = ops.token_logprobs(logits, chosen)
+        cols = [lp[:, None]]
+        if k > 0:
+            topv, topi = torch.topk(logits.float(), k, dim=1)
+            cols += [topi.float(), topv - lse[:, None]]
+        return torch.cat(cols, dim=1)
+
+    @staticmethod
+    def _unpack_logprobs(arr, k: int):
+        """Rows of _logprobs -> per row (chosen logprob, [(token id, logprob)] * k)."""
+        return [(float(r[0]), [(int(r[1 + j]), float(r[1 + k + j])) for j in range(k)]) for r in arr]
+
     def launch_decode(self, batch: int, stage: int = 0, sampling: Optional[dict] = None,
-                      ids_from_device: bool = False) -> None:
+                      ids_from_device: bool = False, logprobs: int = -1) -> None:
         """Enqueues one decode step on the current stream and returns at once: ships
         staging set `stage`, replays the step, copies the sampled ids to the set's
         pinned result buffer.  With `ids_from_device` the input token of row i is
@@ -368,7 +388,8 @@ class ModelRunner:
         leaves the GPU), and only positions, slots, context lengths and block tables
         come from the host: the host can launch step n+1 before it has seen the
         tokens of step n.  `sampling` (numpy arrays temperature/top_k/top_p/seeds/
-        steps, one entry per row) is given only when some row is not greedy."""
+        steps, one entry per row) is given only when some row is not greedy; `logprobs` >= 0 also
+        computes the log-probability of every row's token and of its `logprobs` most likely ones."""
         B = self.max_num_seqs
         if ids_from_device:
             self.in64[B:].copy_(self.h64s[stage][B:], non_blocking=True)
@@ -380,12 +401,19 @@ class ModelRunner:
         if sampling is not None:
             self._sample(self.logits[:batch], sampling, nxt)
         self.h_nexts[stage][:batch].copy_(nxt, non_blocking=True)
+        if logprobs >= 0:
+            self.h_lp[stage][:batch, : 1 + 2 * logprobs].copy_(self._logprobs(self.logits[:batch], nxt, logprobs),
+                                                               non_blocking=True)
         self.done[stage].record()
 
-    def finish_decode(self, batch: int, stage: int = 0):
-        """Waits for the step launched on `stage`; returns its sampled ids as a list."""
+    def finish_decode(self, batch: int, stage: int = 0, logprobs: int = -1):
+        """Waits for the step launched on `stage`; returns its sampled ids as a list (and, with
+        `logprobs` >= 0 as at launch, the per-row log-probabilities from _unpack_logprobs)."""
         self.done[stage].synchronize()
-        return self.h_nexts[stage][:batch].tolist()
+        toks = self.h_nexts[stage][:batch].tolist()
+        if logprobs < 0:
+            return toks
+        return toks, self._unpack_logprobs(self.h_lp[stage][:batch, : 1 + 2 * logprobs].numpy(), logprobs)
 
     def run_decode(self, batch: int, sampling: Optional[dict] = None):
         """One synchronous decode step over staging set 0."""
@@ -393,8 +421,9 @@ class ModelRunner:
         return self.finish_decode(batch, 0)
 
     def run_prefill(self, token_ids, positions, slot_mapping, block_tables, cu_seqlens, context_lens,
-                    max_q_len: int, sampling: Optional[dict] = None):
-        """Host-facing prefill step over numpy inputs; returns next-token ids (list)."""
+                    max_q_len: int, sampling: Optional[dict] = None, logprobs: int = -1):
+        """Host-facing prefill step over numpy inputs; returns next-token ids (list), and with
+        `logprobs` >= 0 also their log-probabilities (as finish_decode)."""
         dev = self.device
 
         def t(a, dt):
@@ -402,9 +431,13 @@ class ModelRunner:
 
         nxt, logits = self.prefill(t(token_ids, torch.int64), t(positions, torch.int64), t(slot_mapping, torch.int64),
                                    t(block_tables, torch.int32), t(cu_seqlens, torch.int32),
-                                   t(context_lens, torch.int32), int(max_q_len), want_logits=sampling is not None)
+                                   t(context_lens, torch.int32), int(max_q_len),
+                                   want_logits=sampling is not None or logprobs >= 0)
         if sampling is not None:
             self._sample(logits, sampling, nxt)
+        if logprobs >= 0:
+            lp = self._logprobs(logits, nxt, logprobs).cpu().numpy()
+            return nxt.cpu().tolist(), self._unpack_logprobs(lp, logprobs)
         return nxt.cpu().tolist()
 
     # ------------------------------------------------------------------ #

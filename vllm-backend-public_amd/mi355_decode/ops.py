@@ -290,6 +290,22 @@ def argmax(logits: torch.Tensor, out: torch.Tensor | None = None):
 LINEAR_DECODE_MAX_M = 128
 
 
+def token_logprobs(logits: torch.Tensor, token_ids: torch.Tensor):
+    """(logprob of token_ids[b] in row b, logsumexp of row b), both float32 [rows]."""
+    _dev(logits, "logits"), _dev(token_ids, "token_ids")
+    ldt = _DT.get(logits.dtype)
+    if ldt is None or logits.dim() != 2 or logits.stride(1) != 1:
+        raise TypeError("logits must be a 2-D bf16/fp16/fp32 tensor with unit column stride")
+    B, V = logits.shape
+    if token_ids.dtype != torch.int64 or token_ids.numel() != B or not token_ids.is_contiguous():
+        raise ValueError("token_ids must be contiguous int64 [rows]")
+    lp = torch.empty(B, dtype=torch.float32, device=logits.device)
+    lse = torch.empty(B, dtype=torch.float32, device=logits.device)
+    check(lib.mi355_token_logprobs(lp.data_ptr(), lse.data_ptr(), logits.data_ptr(), _rows(logits, "logits"), B, V,
+                                   ldt, token_ids.data_ptr(), _stream()))
+    return lp, lse
+
+
 def linear_decode(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None,
                   out: torch.Tensor | None = None, k_slices: int = 0):
     """y = x @ weight.T (+ bias) for decode batches (M <= 128): weights streamed once."""

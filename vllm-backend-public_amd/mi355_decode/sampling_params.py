@@ -32,6 +32,8 @@ class SamplingParams:
         if isinstance(self.stop, str):
             self.stop = [self.stop]
         self.stop = list(self.stop or [])
+        if self.logprobs is not None and not 0 <= int(self.logprobs) <= 20:
+            raise ValueError("logprobs must be between 0 and 20")
         if self.n != 1:
             raise ValueError("n > 1 is not supported")
 
