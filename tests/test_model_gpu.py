@@ -387,3 +387,21 @@ def test_logprobs_through_the_engine_match_the_oracle():
             assert abs(lp - want[0]) <= LOGIT_TOL["bfloat16"] * scale * 2, (i, t, lp, want[0])
             assert len(top) == k and top[0][0] == toks[i][t] and abs(top[0][1] - lp) < 1e-6   # greedy: chosen = most likely
             assert all(top[j][1] >= top[j + 1][1] for j in range(k - 1)) and lp <= 0
+
+
+def test_failed_graph_capture_falls_back_to_eager_launches(monkeypatch):
+    """If the decode step cannot be captured (e.g. a collective the runtime refuses to capture), the
+    engine keeps serving with eager launches and the same tokens."""
+    name = "llama_d64"
+    prompts = make_prompts(name, len(LENGTHS), LENGTHS)
+    eng_ok, _, _ = build(name, "bfloat16")
+    want = engine_generate(eng_ok, prompts, 10)
+    eng, _, _ = build(name, "bfloat16")
+
+    class Refuses:
+        def __init__(self, *a, **k):
+            raise RuntimeError("capture refused (test)")
+    monkeypatch.setattr(torch.cuda, "graph", Refuses)
+    got = engine_generate(eng, prompts, 10)
+    assert eng.runner.use_graphs is False and not eng.runner.graphs
+    np.testing.assert_array_equal(got, want)

@@ -320,21 +320,23 @@ class ModelRunner:
         saved64, saved32 = self.in64.clone(), self.in32.clone()
         self.slots.fill_(-1)
         self.ctx.zero_()
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
+        try:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._decode_body(bucket)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            # with a process group alive, its watchdog thread may touch the HIP runtime while this
+            # thread captures: only calls made by the capturing thread may end the capture
+            mode = "thread_local" if self.tp_size > 1 else "global"
+            with torch.cuda.graph(g, capture_error_mode=mode):
                 self._decode_body(bucket)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        # with a process group alive, its watchdog thread may touch the HIP runtime while this
-        # thread captures: only calls made by the capturing thread may end the capture
-        mode = "thread_local" if self.tp_size > 1 else "global"
-        with torch.cuda.graph(g, capture_error_mode=mode):
-            self._decode_body(bucket)
-        self.in64.copy_(saved64)
-        self.in32.copy_(saved32)
+        finally:                              # whatever happened, the caller's staged inputs come back
+            self.in64.copy_(saved64)
+            self.in32.copy_(saved32)
         self.graphs[bucket] = g
 
     def decode(self, batch: int) -> torch.Tensor:
@@ -347,7 +349,18 @@ class ModelRunner:
             return self.next_ids[:batch]
         bucket = self.bucket_for(batch)
         if bucket not in self.graphs:
-            self.capture(bucket)
+            try:
+                self.capture(bucket)
+            except RuntimeError as exc:
+                # e.g. a collective that cannot be captured on this RCCL build: every rank takes the
+                # same exception at the same step, so all fall back to eager launches together
+                import logging
+                logging.getLogger("mi355_decode").warning(
+                    "HIP-graph capture of the decode step failed (%s); continuing with eager launches", exc)
+                self.use_graphs = False
+                torch.cuda.synchronize()
+                self._decode_body(batch)
+                return self.next_ids[:batch]
         self.graphs[bucket].replay()
         return self.next_ids[:batch]
 
