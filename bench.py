@@ -14,8 +14,9 @@ The timed region starts with all prompts prefilled (K/V resident in HBM) and
 covers exactly K steps; contexts grow from prompt_len+1 as in a real generation,
 and a fresh batch is prefilled (untimed) whenever the sequences reach their
 output length.  With N > 1 GPUs the model runs tensor-parallel over attention
-heads (one process per GPU, RCCL all-reduce on the attention output projection)
-and the batch grows to 32*N sequences (weak scaling, BASELINE.json configs[2]).
+heads and the MLP's intermediate dimension (one process per GPU, RCCL all-reduce
+of the attention output projection and of the down projection; MI355_TP_MLP=0
+keeps the MLP replicated) and the batch grows to 32*N sequences (weak scaling, BASELINE.json configs[2]).
 
 Rank 0 prints ONE JSON line: the contract fields plus
   ttft_ms_p50   time to first token of the batch's prefill (prompt_len*batch tokens)
@@ -60,17 +61,17 @@ def parse():
     return ap.parse_args()
 
 
-def model_bytes(cfg, tp, batch, mean_ctx, elem=2, layer_w_elem=None):
+def model_bytes(cfg, tp, batch, mean_ctx, elem=2, layer_w_elem=None, mlp_tp=1):
     """Algorithmic HBM bytes of one decode step per GPU: every weight once
-    (attention projections sharded over tp, MLP and lm_head replicated), the K/V
-    pages of the mean context, the new K/V rows, and the logits."""
+    (attention projections sharded over tp, the MLP over mlp_tp, lm_head replicated),
+    the K/V pages of the mean context, the new K/V rows, and the logits."""
     H, F, V, L, d = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.num_hidden_layers, cfg.head_dim
     nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
     attn_w = ((nh + 2 * nkv) * d * H + nh * d * H) // tp
-    mlp_w = 3 * F * H
+    mlp_w = 3 * F * H // mlp_tp
     norms = 2 * H
     lw = elem if layer_w_elem is None else layer_w_elem      # fp8: 1 byte per layer weight + fp32 row scales
-    rows = ((nh + 2 * nkv) * d + H) // tp + 2 * F + H
+    rows = ((nh + 2 * nkv) * d + H) // tp + 2 * F // mlp_tp + H
     w_bytes = L * ((attn_w + mlp_w) * lw + norms * elem + (rows * 4 if lw != elem else 0)) + (V * H + H) * elem
     kv_tok = 2 * (nkv // tp) * d * elem * L
     return w_bytes + batch * mean_ctx * kv_tok + batch * kv_tok + batch * V * elem, w_bytes
@@ -124,34 +125,44 @@ def time_kernels(engine, batch, ctx_len):
     W = r.w.layers
     wes = 1 if r.weight_fp8 else es                      # bytes per layer-weight element
     gemm = lambda m, n, k, out_es=es, w_es=None: n * k * (wes if w_es is None else w_es) + m * k * es + m * n * out_es   # noqa: E731
-    tiled = r._use_tiled(b)
-    if tiled:
-        T, P = r.tiled, ops.EPI_PARTIAL
-        plans = r._tiled_plan(b)
-        (tq, gq), (tg, _), (td, gd) = (plans[k] for k in ("qkv", "gu", "down"))
-        to, go = plans.get("o", (0, 1))
-        out["impl"] = ("hand-written weight-streaming GEMMs on fragment-tiled weights (linear_tiled_kernel); "
-                       f"geometry qkv {tq}/{gq}, o {to}/{go}, gate_up {tg}/1 + SwiGLU epilogue, down {td}/{gd}"
-                       + ("" if "o" in plans else "; o projection: hipBLASLt (16-bit output for the all-reduce)"))
-        lt = r._linear_tiled
+    mode = r._mode(b)
+    plans = r._tiled_plan(r.bucket_for(b)) if any(mode.values()) else {}
+    tq, gq = plans.get("qkv", (0, 1))
+    to, go = plans.get("o", (0, 1))
+    tg, _ = plans.get("gu", (0, 1))
+    td, gd = plans.get("down", (0, 1))
+    T, P, lt = r.tiled, ops.EPI_PARTIAL, r._linear_tiled
+    name = {"qkv": "qkv", "o": "o", "gu": "gate_up", "down": "down", "lm_head": "lm_head"}
+    out["impl"] = ("per projection, the faster of the hand-written weight-streaming GEMM on fragment-tiled weights "
+                   "(linear_tiled_kernel, geometry tiles_per_wg/k_groups) and hipBLASLt through torch.mm: "
+                   + ", ".join(f"{name[k]} " + (f"tiled {plans[k][0]}/{plans[k][1]}" if mode[k] else "hipBLASLt")
+                               for k in r.KINDS)
+                   + ("; SwiGLU in the gate_up epilogue" if mode["gu"] else ""))
+    if getattr(r, "tune_us", None):
+        out["tuned_us_tiled_vs_library"] = {name[k]: r.tune_us[(r.bucket_for(b), k)] for k in r.KINDS
+                                            if (r.bucket_for(b), k) in r.tune_us}
+    if mode["gu"]:
         out["gemm_gate_up"] = timed(lambda i: lt(x, T[i]["gu"], 2 * r.F, out=act, tiles_per_wg=tg,
                                                  epilogue=ops.EPI_SILU_MUL),
                                     2 * r.F * r.H * wes + b * r.H * es + b * r.F * es)
+    else:
+        out["gemm_gate_up"] = timed(lambda i: torch.mm(x, W[i].gate_up_w.t(), out=gu), gemm(b, 2 * r.F, r.H, w_es=es))
+        out["silu_and_mul"] = timed(lambda i: ops.silu_and_mul(gu, out=act), 3 * b * r.F * es)
+    if mode["down"]:
         out["gemm_down"] = timed(lambda i: lt(act, T[i]["down"], r.H, partial=r.part_dn, tiles_per_wg=td,
                                               k_groups=gd, epilogue=P), gemm(b, r.H, r.F, 4 * gd))
+    else:
+        out["gemm_down"] = timed(lambda i: torch.mm(act, W[i].down_w.t(), out=dn), gemm(b, r.H, r.F, w_es=es))
+    if mode["qkv"]:
         out["gemm_qkv"] = timed(lambda i: lt(x, T[i]["qkv"], r.qw, partial=r.part_qkv, tiles_per_wg=tq,
                                              k_groups=gq, epilogue=P), gemm(b, r.qw, r.H, 4 * gq))
-        if "o" in plans:
-            out["gemm_o"] = timed(lambda i: lt(attn, T[i]["o"], r.H, partial=r.part_o, tiles_per_wg=to,
-                                               k_groups=go, epilogue=P), gemm(b, r.H, r.nh * r.d, 4 * go))
-        else:
-            out["gemm_o"] = timed(lambda i: torch.mm(attn, W[i].o_w.t(), out=o), gemm(b, r.H, r.nh * r.d))
     else:
-        out["impl"] = "library GEMMs (hipBLASLt through torch.mm) on row-major weights"
-        out["gemm_gate_up"] = timed(lambda i: torch.mm(x, W[i].gate_up_w.t(), out=gu), gemm(b, 2 * r.F, r.H))
-        out["gemm_down"] = timed(lambda i: torch.mm(act, W[i].down_w.t(), out=dn), gemm(b, r.H, r.F))
-        out["gemm_qkv"] = timed(lambda i: torch.mm(x, W[i].qkv_w.t(), out=qkv), gemm(b, r.qw, r.H))
-        out["gemm_o"] = timed(lambda i: torch.mm(attn, W[i].o_w.t(), out=o), gemm(b, r.H, r.nh * r.d))
+        out["gemm_qkv"] = timed(lambda i: torch.mm(x, W[i].qkv_w.t(), out=qkv), gemm(b, r.qw, r.H, w_es=es))
+    if mode["o"]:
+        out["gemm_o"] = timed(lambda i: lt(attn, T[i]["o"], r.H, partial=r.part_o, tiles_per_wg=to,
+                                           k_groups=go, epilogue=P), gemm(b, r.H, r.nh * r.d, 4 * go))
+    else:
+        out["gemm_o"] = timed(lambda i: torch.mm(attn, W[i].o_w.t(), out=o), gemm(b, r.H, r.nh * r.d, w_es=es))
     lm = r.w.lm_head
     out["gemm_lm_head"] = timed(lambda i: r.lm_head_logits(x, r.logits[:b]), gemm(b, r.V, r.H, w_es=es))
 
@@ -160,25 +171,26 @@ def time_kernels(engine, batch, ctx_len):
     ctx_tokens = int(r.ctx[:b].sum().item())              # the device buffers still hold the last step's inputs
     kv_bytes = ctx_tokens * 2 * r.nkv * r.d * es + 2 * b * r.nh * r.d * es
     rope_bytes = b * ((r.nh + r.nkv) * r.d * 2 + r.nkv * r.d + 2 * r.nkv * r.d) * es
-    if tiled:
+    if mode["down"]:
+        out["fused_add_rms_norm"] = timed(
+            lambda i: ops.fused_add_rms_norm_partial(r.part_dn, gd, resid, W[i].post_norm, r.eps, x),
+            b * r.H * (4 * gd + 3 * es))
+    else:
+        out["fused_add_rms_norm"] = timed(lambda i: ops.fused_add_rms_norm(dn, resid, W[i].post_norm, r.eps, out=x),
+                                          5 * b * r.H * es)
+    if mode["qkv"]:
         out["paged_attn_decode_fused"] = timed(
             lambda i: ops.paged_attn_decode_fused(None, r.cos_sin, r.slots[:b], r.k_cache[i], r.v_cache[i],
                                                   r.block_tables[:b], r.ctx[:b], r.nh, r.nkv, r.d, r.scale,
                                                   num_splits=splits, workspace=r.attn_ws, out=attn, partial=r.part_qkv,
                                                   num_slabs=gq, bias=W[i].qkv_b),
             kv_bytes + b * r.qw * 4 * gq + b * 2 * r.nkv * r.d * es)
-        out["fused_add_rms_norm"] = timed(
-            lambda i: ops.fused_add_rms_norm_partial(r.part_dn, gd, resid, W[i].post_norm, r.eps, x),
-            b * r.H * (4 * gd + 3 * es))
     else:
         out["paged_attn_decode_fused"] = timed(
             lambda i: ops.paged_attn_decode_fused(qkv, r.cos_sin, r.slots[:b], r.k_cache[i], r.v_cache[i],
                                                   r.block_tables[:b], r.ctx[:b], r.nh, r.nkv, r.d, r.scale,
                                                   num_splits=splits, workspace=r.attn_ws, out=attn),
             kv_bytes + rope_bytes)
-        out["fused_add_rms_norm"] = timed(lambda i: ops.fused_add_rms_norm(o, resid, W[i].post_norm, r.eps, out=x),
-                                          5 * b * r.H * es)
-        out["silu_and_mul"] = timed(lambda i: ops.silu_and_mul(gu, out=act), 3 * b * r.F * es)
     out["paged_attn_decode_fused"]["splits"] = splits
     out["argmax"] = timed(lambda i: ops.argmax(r.logits[:b], out=r.next_ids[:b]), b * r.V * es)
     return out
@@ -349,12 +361,13 @@ def main():
     tok_s = batch * a.steps / total_t
 
     lwe = 1 if a.quantization == "fp8" else None
-    step_bytes, w_bytes = model_bytes(cfg, tp, batch, mean_ctx, layer_w_elem=lwe)
+    mlp_tp = tp if engine.runner.mlp_sharded else 1
+    step_bytes, w_bytes = model_bytes(cfg, tp, batch, mean_ctx, layer_w_elem=lwe, mlp_tp=mlp_tp)
     if a.layers:
         import copy
         c2 = copy.copy(cfg)
         c2.num_hidden_layers = a.layers
-        step_bytes, w_bytes = model_bytes(c2, tp, batch, mean_ctx, layer_w_elem=lwe)
+        step_bytes, w_bytes = model_bytes(c2, tp, batch, mean_ctx, layer_w_elem=lwe, mlp_tp=mlp_tp)
     step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
 
     result = {
@@ -365,7 +378,9 @@ def main():
         "config": {"workload": f"{a.model} decode, batch {batch} ({a.batch_per_gpu}/GPU), {P}-in/{G}-out, greedy, "
                                f"synthetic weights and token-id prompts; BASELINE.json configs[{1 if a.gpus == 1 else 2}]",
                    "global_batch": batch, "prompt_len": P, "gen_len": G,
-                   "parallelism": f"tp{tp} (attention heads sharded, MLP+lm_head replicated)" if tp > 1 else "tp1",
+                   "parallelism": (f"tp{tp} (attention heads and MLP sharded, two all-reduces per layer; lm_head "
+                                   f"replicated)" if mlp_tp > 1 else
+                                   f"tp{tp} (attention heads sharded, MLP+lm_head replicated)") if tp > 1 else "tp1",
                    "mean_context": round(mean_ctx, 1), "hip_graphs": not a.eager},
         "ttft_ms_p50": round(ttft_ms, 2),
         "step_roofline": {"bound": "hbm", "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -379,7 +394,7 @@ def main():
         kern = time_kernels(engine, batch, int(mean_ctx))
         result["kernels"] = kern
         dom = kern["gemm_gate_up"]
-        tiled = kern["impl"].startswith("hand-written")
+        tiled = engine.runner._mode(batch)["gu"]
         traffic, src = pmc_traffic(tiled)
         result["roofline"] = {"bound": "hbm",
                               "kernel": ("gate/up projection GEMM%s (M=%d, N=%d, K=%d): %s" % (

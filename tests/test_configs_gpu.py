@@ -16,11 +16,13 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 CASES = [
-    # name, model, tp, rank, batch, context, max_model_len
-    ("cfg1", "llama-3-8b", 1, 0, 32, 200, 256),
-    ("cfg2", "llama-3-8b", 4, 2, 128, 200, 256),
-    ("cfg3", "llama-3-70b", 8, 5, 16, 2100, 2304),
-    ("cfg4", "qwen2-7b", 1, 0, 64, 700, 1024),
+    # name, model, tp, rank, batch, context, max_model_len, MLP sharded over the ranks
+    ("cfg1", "llama-3-8b", 1, 0, 32, 200, 256, False),
+    ("cfg2", "llama-3-8b", 4, 2, 128, 200, 256, False),
+    ("cfg2_mlp_sharded", "llama-3-8b", 4, 2, 128, 200, 256, True),
+    ("cfg3", "llama-3-70b", 8, 5, 16, 2100, 2304, False),
+    ("cfg3_mlp_sharded", "llama-3-70b", 8, 5, 16, 2100, 2304, True),
+    ("cfg4", "qwen2-7b", 1, 0, 64, 700, 1024, False),
 ]
 
 
@@ -29,16 +31,17 @@ def test_rank_decode_step_tiled_vs_library(case, monkeypatch):
     from mi355_decode import weights as W
     from mi355_decode.config import ModelConfig
     from mi355_decode.model_runner import ModelRunner
-    _, model, tp, rank, batch, ctx, max_len = case
+    _, model, tp, rank, batch, ctx, max_len, shard_mlp = case
     cfg = ModelConfig.from_pretrained(model)
     blocks_per_seq = (max_len + 15) // 16
     out = {}
     for tiled in (True, False):
-        ws = W.synthetic(cfg, torch.bfloat16, "cuda", seed=5, tp_rank=rank, tp_size=tp, num_layers=2, std=0.03)
+        ws = W.synthetic(cfg, torch.bfloat16, "cuda", seed=5, tp_rank=rank, tp_size=tp, num_layers=2, std=0.03,
+                         shard_mlp=shard_mlp)
         r = ModelRunner(cfg, ws, torch.bfloat16, "cuda", num_blocks=batch * blocks_per_seq, max_num_seqs=batch,
                         max_model_len=max_len, tp_rank=rank, tp_size=tp, tp_group=None, tiled_linears=tiled)
         monkeypatch.setattr(r, "_allreduce", lambda t: None)      # this rank's share only
-        assert r._use_tiled(r.bucket_for(batch)) == tiled
+        assert r._use_tiled(r.bucket_for(batch)) == tiled and r.mlp_sharded == shard_mlp
         g = torch.Generator(device="cuda").manual_seed(11)
         for kc, vc in zip(r.k_cache, r.v_cache):
             kc.normal_(0, 1.0, generator=g)

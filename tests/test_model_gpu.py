@@ -258,11 +258,13 @@ def test_tiled_and_library_gemm_paths_both_match_oracle(name, monkeypatch):
     """The decode step on fragment-tiled weights (K-split GEMMs feeding the norm and
     rotary kernels in partial-sum form, SwiGLU in the GEMM epilogue) and the step on
     library GEMMs are two implementations of the same arithmetic: each is held to the
-    oracle, and the tiled one must really be the one that ran by default."""
+    oracle, and the forced tiled run must really have taken the tiled kernels."""
     prompts = make_prompts(name, len(LENGTHS), LENGTHS)
+    monkeypatch.setenv("MI355_TILED_LINEARS", "1")      # every projection on its tiled kernel, no timing-based choice
     eng_t, cfg, w = build(name, "bfloat16")
     assert eng_t.runner.tiled is not None, "tiled decode path not active for an eligible model"
     got_t = _oracle_checked(eng_t, cfg, w, prompts, 16, f"{name} tiled")
+    assert all(eng_t.runner._mode(len(prompts)).values())
     monkeypatch.setenv("MI355_TILED_LINEARS", "0")
     eng_l, _, _ = build(name, "bfloat16")
     assert eng_l.runner.tiled is None
@@ -270,16 +272,35 @@ def test_tiled_and_library_gemm_paths_both_match_oracle(name, monkeypatch):
     assert (got_t[:, 0] == got_l[:, 0]).all()          # first token comes from the shared prefill path
 
 
+def test_timing_based_choice_of_gemm_form_matches_oracle():
+    """The serving default: the first step of a batch-size bucket times every projection as the
+    tiled kernel and as a library GEMM and keeps the faster form.  Whatever mix it picks is
+    held to the oracle like the two pure paths."""
+    name = "llama_d128"
+    prompts = make_prompts(name, len(LENGTHS), LENGTHS)
+    eng, cfg, w = build(name, "bfloat16")
+    r = eng.runner
+    assert r.tiled_policy == "auto" and r.tiled is not None
+    _oracle_checked(eng, cfg, w, prompts, 16, f"{name} auto")
+    bucket = r.bucket_for(len(prompts))
+    assert bucket in r._modes and set(r._modes[bucket]) == set(r.KINDS)
+    timed = {k: r.tune_us[(bucket, k)] for k in r.KINDS}
+    print(f"bucket {bucket}: (tiled us, library us) {timed} -> {r._modes[bucket]}")
+    for k, (tt, tl) in timed.items():
+        assert tt > 0 and tl > 0 and r._modes[bucket][k] == (tt <= tl)
+
+
 @pytest.mark.parametrize("nseq", [40, 72])
-def test_batches_of_33_to_128_rows_match_oracle(nseq):
+def test_batches_of_33_to_128_rows_match_oracle(nseq, monkeypatch):
     """Decode batches beyond 32 rows take the 4- and 8-m-tile GEMM kernels."""
     name = "llama_d128"
+    monkeypatch.setenv("MI355_TILED_LINEARS", "1")
     rng = np.random.Generator(np.random.PCG64(nseq))
     lengths = rng.integers(3, 30, nseq).tolist()
     prompts = make_prompts(name, nseq, lengths, seed=7)
     eng, cfg, w = build(name, "bfloat16", max_num_seqs=nseq)
     r = eng.runner
-    assert r._use_tiled(r.bucket_for(nseq)), "tiled decode path not active at this batch size"
+    assert all(r._mode(nseq).values()), "tiled decode path not active at this batch size"
     ref_tokens, ref_logits = M.greedy_generate(
         M.RefModel(M.RefConfig(**cfg), w, "bfloat16", num_blocks=nseq * 8), prompts, 6)
     scale = np.abs(ref_logits[0]).max()
@@ -327,7 +348,7 @@ def test_tensor_parallel_rank_step_tiled_vs_library(batch, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["llama_d128", "qwen2_d128"])
-def test_fp8_weights_engine_matches_oracle_on_the_quantised_model(name):
+def test_fp8_weights_engine_matches_oracle_on_the_quantised_model(name, monkeypatch):
     """--quantization fp8: the engine (fp8 weight stream at decode, dequantised 16-bit copies at
     prefill) against the oracle run on the same quantised model, w' = fp8(w / scale) * scale per
     weight row with scale = max|row| / 448."""
@@ -341,6 +362,7 @@ def test_fp8_weights_engine_matches_oracle_on_the_quantised_model(name):
         else:
             wq[k] = v
     prompts = make_prompts(name, len(LENGTHS), LENGTHS)
+    monkeypatch.setenv("MI355_TILED_LINEARS", "1")      # the fp8 stream is the subject: no timing-based fallback to library GEMMs
     eng, _, _ = build(name, "bfloat16", quantization="fp8")
     assert eng.runner.weight_fp8 and isinstance(eng.runner.tiled[0]["qkv"], tuple), "fp8 weight stream not active"
     ref_tokens, ref_logits = oracle_run(cfg, wq, "bfloat16", prompts, 16)

@@ -58,6 +58,23 @@ def _shard_worker(rank, world, port, q):
         partial = attn_mine @ lw.o_w.t()
         dist.all_reduce(partial)
         assert torch.allclose(partial, attn_full @ fw.o_w.t(), atol=1e-4)
+        # sharded MLP: rows of gate/up and columns of down; SwiGLU is elementwise over the
+        # intermediate dimension, so the all-reduced partial sums are the full MLP output
+        sh = W.from_state_dict(mc, sd, torch.float32, "cpu", tp_rank=rank, tp_size=world, shard_mlp=True)
+        F = mc.intermediate_size
+        Fl = F // world
+        sw = sh.layers[0]
+        assert sw.gate_up_w.shape == (2 * Fl, H) and sw.down_w.shape == (H, Fl)
+        assert torch.equal(sw.gate_up_w[:Fl], fw.gate_up_w[rank * Fl:(rank + 1) * Fl])
+        assert torch.equal(sw.gate_up_w[Fl:], fw.gate_up_w[F + rank * Fl:F + (rank + 1) * Fl])
+        assert torch.equal(sw.qkv_w, lw.qkv_w) and torch.equal(sh.lm_head, full.lm_head)
+
+        def mlp(wl, fl):
+            gu = x @ wl.gate_up_w.t()
+            return (torch.nn.functional.silu(gu[:, :fl]) * gu[:, fl:]) @ wl.down_w.t()
+        part = mlp(sw, Fl)
+        dist.all_reduce(part)
+        assert torch.allclose(part, mlp(fw, F), atol=1e-4)
         q.put((rank, "ok"))
     except Exception as exc:  # noqa: BLE001
         q.put((rank, repr(exc)))

@@ -1,0 +1,98 @@
+"""Tensor parallelism end to end on ONE GPU: two engine processes (rank 0 and 1 of a
+TP=2 group) share the card and exchange their partial sums over gloo -- RCCL refuses two
+ranks on one device, and gloo cannot be graph-captured, so the steps run eagerly.  What is
+pinned: the head and MLP sharding of the weights, both all-reduce call sites, the
+lock-step of the two schedulers, and the generated tokens against the numpy oracle of the
+unsharded model (a sharded sum rounds differently: a sequence may leave the oracle at a
+near-tie of the oracle's own logits, as in test_model_gpu)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEN = 16
+LENGTHS = [5, 16, 17, 33]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, name, dtype, shard_mlp, q):
+    try:
+        for p in (ROOT, os.path.join(ROOT, "vllm-backend-public_amd"), os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK="0", MI355_DIST_BACKEND="gloo", MI355_TP_MLP="1" if shard_mlp else "0")
+        import torch
+        import torch.distributed as dist
+        from test_model_gpu import build, engine_generate
+        from oracle.tiny_models import make_prompts
+        eng, cfg, w = build(name, dtype, tensor_parallel_size=world, enforce_eager=True)
+        r = eng.runner
+        assert r.tp_size == world and r.mlp_sharded == shard_mlp
+        assert r.F * (world if shard_mlp else 1) == cfg["intermediate_size"]
+        calls = [0]
+        inner = r._allreduce
+
+        def counted(t):
+            calls[0] += 1
+            inner(t)
+        r._allreduce = counted
+        toks = engine_generate(eng, make_prompts(name, len(LENGTHS), LENGTHS), GEN)
+        steps = eng.stats["decode_steps"] + eng.stats["prefill_steps"]
+        per_step = r.L * (2 if shard_mlp else 1)               # a step launched ahead may not be counted yet
+        assert calls[0] % per_step == 0 and calls[0] >= steps * per_step, (calls[0], steps)
+        q.put((rank, "ok", toks.tolist()))
+        dist.barrier()
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc(), None))
+    finally:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shard_mlp", [True, False], ids=["mlp_sharded", "mlp_replicated"])
+@pytest.mark.parametrize("name,dtype", [("llama_d128", "bfloat16"), ("qwen2_d128", "float16")])
+def test_two_ranks_generate_like_the_unsharded_oracle(name, dtype, shard_mlp):
+    import torch.multiprocessing as mp
+    from oracle import ops_ref as R
+    from oracle.tiny_models import make_prompts, make_weights
+    from test_model_gpu import LOGIT_TOL, compare_tokens, oracle_run
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, dtype, shard_mlp, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted(q.get(timeout=240) for _ in procs)
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
+    for rank, msg, _ in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+    t0, t1 = np.array(res[0][2]), np.array(res[1][2])
+    assert np.array_equal(t0, t1), "the two ranks sampled different tokens"
+    _, cfg, w = make_weights(name)
+    w = {k: R.round_to(v, dtype) for k, v in w.items()}
+    ref_tokens, ref_logits = oracle_run(cfg, w, dtype, make_prompts(name, len(LENGTHS), LENGTHS), GEN)
+    scale = np.abs(ref_logits[0]).max()
+    exact = compare_tokens(t0, ref_tokens, ref_logits, 2 * LOGIT_TOL[dtype] * scale)
+    print(f"{name} {dtype} tp2 {'mlp sharded' if shard_mlp else 'mlp replicated'}: "
+          f"{exact}/{ref_tokens.size} tokens equal to the unsharded oracle")
+    assert exact >= 0.6 * ref_tokens.size

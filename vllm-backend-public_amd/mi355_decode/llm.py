@@ -22,7 +22,9 @@ TORCH_DTYPE = {"bfloat16": torch.bfloat16, "float16": torch.float16}
 
 
 def init_distributed(tp_size: int):
-    """One process per GPU.  Returns (rank, world, device, group)."""
+    """One process per GPU.  Returns (rank, world, device, group).  MI355_DIST_BACKEND=gloo swaps
+    RCCL for gloo (collectives staged through the host, not graph-capturable: with
+    --enforce-eager it lets several ranks rehearse on one GPU, which RCCL refuses)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -33,7 +35,11 @@ def init_distributed(tp_size: int):
         device = torch.device("cuda", local)
         torch.cuda.set_device(device)
         if not torch.distributed.is_initialized():
-            torch.distributed.init_process_group("nccl", device_id=device)
+            backend = os.environ.get("MI355_DIST_BACKEND", "nccl")
+            if backend == "nccl":
+                torch.distributed.init_process_group("nccl", device_id=device)
+            else:
+                torch.distributed.init_process_group(backend)
         return rank, world, device, torch.distributed.group.WORLD
     device = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(device)
@@ -75,7 +81,11 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
                     args.block_size, BLOCK_SIZE)
     max_model_len = args.max_model_len or min(cfg.max_position_embeddings, 8192)
     nl = args.num_layers_override
-    kw = dict(tp_rank=rank, tp_size=world if args.tensor_parallel_size > 1 else 1, num_layers=nl)
+    tp = world if args.tensor_parallel_size > 1 else 1
+    # MI355_TP_MLP=0 keeps the MLP replicated under tensor parallelism (one all-reduce per layer
+    # instead of two, at N times the MLP weight bytes per GPU)
+    shard_mlp = tp > 1 and os.environ.get("MI355_TP_MLP", "1") != "0" and cfg.intermediate_size % (32 * tp) == 0
+    kw = dict(tp_rank=rank, tp_size=tp, num_layers=nl, shard_mlp=shard_mlp)
     if state_dict is not None:
         weights = W.from_state_dict(cfg, state_dict, dtype, device, **kw)
     elif args.load_format != "dummy" and W.has_checkpoint(args.model):
@@ -85,12 +95,12 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
             log.warning("no *.safetensors under %r: using seeded synthetic weights (nothing is downloaded)",
                         args.model)
         weights = W.synthetic(cfg, dtype, device, seed=args.seed, **kw)
-    tp = kw["tp_size"]
     # the runner keeps a second, fragment-tiled copy of the decode-time matrices (the o
     # projection only without tensor parallelism)
     fp8 = (args.quantization or "").lower() == "fp8"
     tiled_bytes = sum(t.numel() * (1 if fp8 else t.element_size()) for lw in weights.layers
-                      for t in (lw.qkv_w, lw.gate_up_w, lw.down_w) + ((lw.o_w,) if tp == 1 else ()))
+                      for t in (lw.qkv_w, lw.gate_up_w) + ((lw.o_w,) if tp == 1 else ())
+                      + (() if shard_mlp else (lw.down_w,)))
     tiled_bytes += weights.lm_head.numel() * weights.lm_head.element_size()
     num_blocks = plan_num_blocks(args, cfg, tp, len(weights.layers), max_model_len,
                                  torch.empty(0, dtype=dtype).element_size(), device, extra_reserve=tiled_bytes)

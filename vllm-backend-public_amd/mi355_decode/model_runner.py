@@ -66,7 +66,14 @@ class ModelRunner:
         self.nh = cfg.num_attention_heads // tp_size
         self.nkv = cfg.num_key_value_heads // tp_size
         self.d = cfg.head_dim
-        self.H, self.F, self.V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+        self.H, self.V = cfg.hidden_size, cfg.vocab_size
+        # the weights say whether this rank holds the whole MLP or its 1/tp_size slice of the
+        # intermediate dimension (then down_proj's partial sums are all-reduced like o_proj's)
+        self.F = int(weights.layers[0].down_w.shape[1]) if weights.layers else cfg.intermediate_size
+        self.mlp_sharded = self.F != cfg.intermediate_size
+        if self.mlp_sharded and self.F * tp_size != cfg.intermediate_size:
+            raise ValueError(f"MLP slice of {self.F} columns does not match intermediate_size "
+                             f"{cfg.intermediate_size} / tensor_parallel_size {tp_size}")
         self.L = len(weights.layers)
         self.qw = (self.nh + 2 * self.nkv) * self.d
         self.scale = self.d ** -0.5
@@ -133,49 +140,62 @@ class ModelRunner:
         self.h64, self.h32, self.h_next = self.h64s[0], self.h32s[0], self.h_nexts[0]
 
     # ------------------------------------------------------------------ #
+    KINDS = ("qkv", "o", "gu", "down", "lm_head")
+
     def _init_tiled(self, want: Optional[bool]) -> None:
         """Fragment-tiled copies of the weights for decode batches of up to 128 rows.
-        Under tensor parallelism the o projection stays a library GEMM: its output has to
-        be a 16-bit tensor for the all-reduce, and the K-split kernel's strength is handing
-        fp32 partial sums to the next kernel."""
+        A projection whose output is all-reduced (o under tensor parallelism, down when the
+        MLP is sharded) stays a library GEMM: its output has to be a 16-bit tensor for the
+        collective, and the K-split kernel's strength is handing fp32 partial sums to the next
+        kernel.
+
+        `want` True: every projection that has a tiled kernel for the step's row count uses it;
+        False: library GEMMs only; None (the serving default, MI355_TILED_LINEARS=1/0 forces
+        either): the first step of each batch-size bucket times both forms of every projection
+        on this GPU and keeps the faster one (wide batches on narrow tensor-parallel slices
+        launch too few workgroups for the streaming kernel to win)."""
         import os
-        if want is None:
-            want = os.environ.get("MI355_TILED_LINEARS", "1") != "0"
+        self.tiled_policy = {True: "on", False: "off", None: "auto"}[want]
+        if want is None and os.environ.get("MI355_TILED_LINEARS") in ("0", "1"):
+            self.tiled_policy = "on" if os.environ["MI355_TILED_LINEARS"] == "1" else "off"
         self.tiled = None
-        if not want or self.dtype not in (torch.bfloat16, torch.float16) or (2 * self.F) % 32:
+        self._modes = {}
+        self._plan_cache = {}
+        self.tiled_shapes = {}
+        if self.tiled_policy == "off" or self.dtype not in (torch.bfloat16, torch.float16) or (2 * self.F) % 32:
             return
         self.tiled_shapes = {"qkv": (self.qw, self.H, True), "gu": (2 * self.F, self.H, False),
-                             "down": (self.H, self.F, True), "lm_head": (self.V, self.H, False)}
+                             "lm_head": (self.V, self.H, False)}
         if self.tp_size == 1:
             self.tiled_shapes["o"] = (self.H, self.nh * self.d, True)
-        self._plan_cache = {}
-        self.tiled_max_m = 0
-        for m in (16, 32, 64, 128):                   # largest row count every layer has a kernel for
-            if self._tiled_plan(m) is None:
+        if not self.mlp_sharded:
+            self.tiled_shapes["down"] = (self.H, self.F, True)
+        ms = []                                       # the kernels' row-count classes a bucket can fall in
+        for m in (16, 32, 64, 128):
+            ms.append(m)
+            if m >= self.max_num_seqs:
                 break
-            self.tiled_max_m = m
-        self.tiled_max_m = min(self.tiled_max_m, self.max_num_seqs)
-        if self.tiled_max_m == 0:
+        # projections with no kernel at any row count are not tiled at all
+        self.tiled_shapes = {k: v for k, v in self.tiled_shapes.items() if any(k in self._tiled_plan(m) for m in ms)}
+        if not self.tiled_shapes:
             return
         self.tiled = []
         # fp8: (bytes, row scales) per matrix instead of a 16-bit tiled tensor; the lm_head stays 16-bit
         tile = ops.tile_weights_fp8 if self.weight_fp8 else ops.tile_weights
+        src = {"qkv": "qkv_w", "o": "o_w", "gu": "gate_up_w", "down": "down_w"}
         for lw in self.w.layers:
-            tw = {"qkv": tile(lw.qkv_w), "gu": tile(lw.gate_up_w, interleave_halves=True), "down": tile(lw.down_w)}
-            if self.tp_size == 1:
-                tw["o"] = tile(lw.o_w)
-            self.tiled.append(tw)
-        self.lm_head_tiled = ops.tile_weights(self.w.lm_head)
+            self.tiled.append({k: tile(getattr(lw, src[k]), interleave_halves=(k == "gu"))
+                               for k in src if k in self.tiled_shapes})
+        self.lm_head_tiled = ops.tile_weights(self.w.lm_head) if "lm_head" in self.tiled_shapes else None
         f32 = dict(dtype=torch.float32, device=self.device)
         size = {k: 0 for k in ("qkv", "o", "down")}
-        for m in (16, 32, 64, 128):
-            m = min(m, self.tiled_max_m)
+        for m in ms:
             for k in size:
-                if k in self.tiled_shapes:
+                if k in self._tiled_plan(m):
                     size[k] = max(size[k], self._tiled_plan(m)[k][1] * m * self.tiled_shapes[k][0])
-        self.part_qkv = torch.empty(size["qkv"], **f32)
+        self.part_qkv = torch.empty(max(size["qkv"], 4), **f32)
         self.part_o = torch.empty(max(size["o"], 4), **f32)
-        self.part_dn = torch.empty(size["down"], **f32)
+        self.part_dn = torch.empty(max(size["down"], 4), **f32)
 
     def _fake_quantize_row_major(self) -> None:
         """--quantization fp8: the row-major matrices (prefill, large batches, the TP o projection) are
@@ -197,49 +217,196 @@ class ModelRunner:
         return ops.linear_tiled(x, w, N, **kw)
 
     def _tiled_plan(self, m: int):
-        """{layer: (tiles_per_wg, k_groups)} for m rows, or None if some layer has no kernel."""
+        """{projection: (tiles_per_wg, k_groups)} of the projections that have a tiled kernel for m rows."""
         if m not in self._plan_cache:
-            plans = {k: ops.plan_linear_tiled(n, kk, split, m) for k, (n, kk, split) in self.tiled_shapes.items()}
-            self._plan_cache[m] = None if any(p is None for p in plans.values()) else plans
+            plans = {}
+            if m <= ops.LINEAR_TILED_MAX_M:
+                plans = {k: ops.plan_linear_tiled(n, kk, split, m) for k, (n, kk, split) in self.tiled_shapes.items()}
+            self._plan_cache[m] = {k: p for k, p in plans.items() if p is not None}
         return self._plan_cache[m]
 
-    def _use_tiled(self, b: int) -> bool:
-        return self.tiled is not None and b <= self.tiled_max_m and self._tiled_plan(b) is not None
+    def _mode(self, b: int) -> dict:
+        """{projection: True if its decode GEMM at b rows is the tiled kernel}.  Fixed per
+        batch-size bucket, so a bucket's graph and its eager steps agree."""
+        m = self.bucket_for(b) if b <= self.max_num_seqs else b
+        if m not in self._modes:
+            avail = self._tiled_plan(m) if self.tiled is not None else {}
+            # until a bucket is tuned (or when tuning is off) every available kernel is used
+            return {k: k in avail for k in self.KINDS}
+        return self._modes[m]
 
-    def _decode_layers_tiled(self, b: int, pos, slots, bt, ctx, splits) -> None:
-        """All decoder layers + the final norm for b <= 128 decode tokens on the tiled
-        weights; leaves the normed hidden state in self.x[:b]."""
+    def _use_tiled(self, b: int) -> bool:
+        """True if any projection of a b-row decode step runs on the tiled kernels."""
+        return any(self._mode(b).values())
+
+    def _time_launches(self, fn) -> float:
+        """Average GPU time (us) of fn(layer), replayed from a graph that walks the layers."""
+        reps = max(1, 32 // max(self.L, 1))
+        fn(0)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local" if self.tp_size > 1 else "global"):
+            for _ in range(reps):
+                for i in range(self.L):
+                    fn(i)
+        g.replay()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        g.replay()
+        g.replay()
+        e.record()
+        e.synchronize()
+        return s.elapsed_time(e) * 1e3 / (2 * reps * self.L)
+
+    def tune(self, bucket: int) -> dict:
+        """Decides, for one batch-size bucket, which projections run on the tiled kernels: times
+        each one both ways (GEMM plus the consumer kernel whose input format it changes) on
+        scratch activations and neutral step inputs.  Under tensor parallelism rank 0's decisions are broadcast: the
+        replicated projections must round the same way on every rank, or the ranks' greedy
+        tokens could part."""
+        if bucket in self._modes:
+            return self._modes[bucket]
+        avail = self._tiled_plan(bucket) if self.tiled is not None else {}
+        mode = {k: k in avail for k in self.KINDS}
+        if self.tiled_policy == "auto" and avail:
+            b = bucket
+            # neutral step inputs while timing (no KV store, empty contexts); the staged ones come back after
+            saved64, saved32 = self.in64.clone(), self.in32.clone()
+            self.slots.fill_(-1)
+            self.in32.zero_()
+            slots, ctx, bt, splits = self.slots[:b], self.ctx[:b], self.block_tables[:b], self._splits_for(b)
+
+            def attend(i, **kw):
+                ops.paged_attn_decode_fused(kw.pop("qkv", None), self.cos_sin, slots, self.k_cache[i], self.v_cache[i],
+                                            bt, ctx, self.nh, self.nkv, self.d, self.scale, num_splits=splits,
+                                            workspace=self.attn_ws, out=attn, **kw)
+            resid, x, qkv, attn, act, o, gu, dn = (t[:b] for t in (self.resid, self.x, self.qkv, self.attn, self.act,
+                                                                  self.o, self.gu, self.dn))
+            W, T, P, eps = self.w.layers, self.tiled, ops.EPI_PARTIAL, self.eps
+            lt = self._linear_tiled
+            forms = {}
+            if "qkv" in avail:
+                t_, g_ = avail["qkv"]
+                forms["qkv"] = (lambda i: (lt(x, T[i]["qkv"], self.qw, partial=self.part_qkv, tiles_per_wg=t_,
+                                              k_groups=g_, epilogue=P),
+                                           attend(i, partial=self.part_qkv, num_slabs=g_, bias=W[i].qkv_b)),
+                                lambda i: (torch.mm(x, W[i].qkv_w.t(), out=qkv), attend(i, qkv=qkv)))
+            if "o" in avail:
+                to, go = avail["o"]
+                forms["o"] = (lambda i: (lt(attn, T[i]["o"], self.H, partial=self.part_o, tiles_per_wg=to, k_groups=go,
+                                            epilogue=P),
+                                         ops.fused_add_rms_norm_partial(self.part_o, go, resid, W[i].post_norm, eps, x)),
+                              lambda i: (torch.mm(attn, W[i].o_w.t(), out=o),
+                                         ops.fused_add_rms_norm(o, resid, W[i].post_norm, eps, out=x)))
+            if "gu" in avail:
+                tg = avail["gu"][0]
+                forms["gu"] = (lambda i: lt(x, T[i]["gu"], 2 * self.F, out=act, tiles_per_wg=tg,
+                                            epilogue=ops.EPI_SILU_MUL),
+                               lambda i: (torch.mm(x, W[i].gate_up_w.t(), out=gu), ops.silu_and_mul(gu, out=act)))
+            if "down" in avail:
+                td, gd = avail["down"]
+                forms["down"] = (lambda i: (lt(act, T[i]["down"], self.H, partial=self.part_dn, tiles_per_wg=td,
+                                               k_groups=gd, epilogue=P),
+                                            ops.fused_add_rms_norm_partial(self.part_dn, gd, resid, W[i].input_norm, eps, x)),
+                                 lambda i: (torch.mm(act, W[i].down_w.t(), out=dn),
+                                            ops.fused_add_rms_norm(dn, resid, W[i].input_norm, eps, out=x)))
+            if "lm_head" in avail:
+                th = avail["lm_head"][0]
+                forms["lm_head"] = (lambda i: ops.linear_tiled(x, self.lm_head_tiled, self.V, out=self.logits[:b],
+                                                               tiles_per_wg=th),
+                                    lambda i: torch.mm(x, self.w.lm_head.t(), out=self.logits[:b]))
+            self.tune_us = getattr(self, "tune_us", {})
+            try:
+                for k, (tiled_fn, lib_fn) in forms.items():
+                    lib_fn(0)                               # first library call may pick its algorithm
+                    tt, tl = self._time_launches(tiled_fn), self._time_launches(lib_fn)
+                    self.tune_us[(bucket, k)] = (round(tt, 2), round(tl, 2))
+                    mode[k] = tt <= tl
+            except RuntimeError as exc:                     # timing replays graphs: without them, no choice is made
+                import logging
+                logging.getLogger("mi355_decode").warning(
+                    "timing the GEMM forms for batch bucket %d failed (%s); using the tiled kernels", bucket, exc)
+                torch.cuda.synchronize()
+                mode = {k: k in avail for k in self.KINDS}
+            resid.zero_()                                   # the timed norms accumulated into it
+            self.in64.copy_(saved64)
+            self.in32.copy_(saved32)
+        if self.tp_size > 1 and self.tp_group is not None:
+            flags = torch.tensor([int(mode[k]) for k in self.KINDS], dtype=torch.int32, device=self.device)
+            torch.distributed.broadcast(flags, src=0, group=self.tp_group)
+            mode = {k: bool(v) for k, v in zip(self.KINDS, flags.tolist())}
+        self._modes[bucket] = mode
+        return mode
+
+    def _decode_layers(self, b: int, slots, bt, ctx, splits) -> None:
+        """All decoder layers + the final norm for b decode tokens held in self.resid[:b]; leaves the
+        normed hidden state in self.x[:b].  Each projection runs as the tiled kernel or as a library
+        GEMM as self._mode(b) says; a K-split tiled projection hands fp32 partial sums to the kernel
+        after it (attention, norm), a library one a 16-bit tensor."""
         resid, x, qkv, attn, act, o = self.resid[:b], self.x[:b], self.qkv[:b], self.attn[:b], self.act[:b], self.o[:b]
+        gu, dn = self.gu[:b], self.dn[:b]
         P = ops.EPI_PARTIAL
-        plans = self._tiled_plan(b)
-        (tq, gq), (tg, _), (td, gd) = (plans[k] for k in ("qkv", "gu", "down"))
-        for i, (lw, tw) in enumerate(zip(self.w.layers, self.tiled)):
+        mode = self._mode(b)
+        plans = self._tiled_plan(self.bucket_for(b)) if any(mode.values()) else {}
+        tq, gq = plans.get("qkv", (0, 1))
+        to, go = plans.get("o", (0, 1))
+        tg, _ = plans.get("gu", (0, 1))
+        td, gd = plans.get("down", (0, 1))
+        tiled = self.tiled if self.tiled is not None else [None] * self.L
+
+        def add_mlp_and_norm(weight):
+            if mode["down"]:
+                ops.fused_add_rms_norm_partial(self.part_dn, gd, resid, weight, self.eps, x)
+            else:
+                ops.fused_add_rms_norm(dn, resid, weight, self.eps, out=x)
+
+        for i, (lw, tw) in enumerate(zip(self.w.layers, tiled)):
             if i == 0:
                 ops.rms_norm(resid, lw.input_norm, self.eps, out=x)
             else:
-                ops.fused_add_rms_norm_partial(self.part_dn, gd, resid, lw.input_norm, self.eps, x)
-            self._linear_tiled(x, tw["qkv"], self.qw, partial=self.part_qkv, tiles_per_wg=tq, k_groups=gq, epilogue=P)
-            ops.paged_attn_decode_fused(None, self.cos_sin, slots, self.k_cache[i], self.v_cache[i], bt, ctx,
-                                        self.nh, self.nkv, self.d, self.scale, num_splits=splits,
-                                        workspace=self.attn_ws, out=attn, partial=self.part_qkv, num_slabs=gq,
-                                        bias=lw.qkv_b)
-            if self.tp_size == 1:
-                to, go = plans["o"]
+                add_mlp_and_norm(lw.input_norm)
+            if mode["qkv"]:
+                self._linear_tiled(x, tw["qkv"], self.qw, partial=self.part_qkv, tiles_per_wg=tq, k_groups=gq,
+                                   epilogue=P)
+                ops.paged_attn_decode_fused(None, self.cos_sin, slots, self.k_cache[i], self.v_cache[i], bt, ctx,
+                                            self.nh, self.nkv, self.d, self.scale, num_splits=splits,
+                                            workspace=self.attn_ws, out=attn, partial=self.part_qkv, num_slabs=gq,
+                                            bias=lw.qkv_b)
+            else:
+                if lw.qkv_b is None:
+                    torch.mm(x, lw.qkv_w.t(), out=qkv)
+                else:
+                    torch.addmm(lw.qkv_b, x, lw.qkv_w.t(), out=qkv)
+                ops.paged_attn_decode_fused(qkv, self.cos_sin, slots, self.k_cache[i], self.v_cache[i], bt, ctx,
+                                            self.nh, self.nkv, self.d, self.scale, num_splits=splits,
+                                            workspace=self.attn_ws, out=attn)
+            if mode["o"]:
                 self._linear_tiled(attn, tw["o"], self.H, partial=self.part_o, tiles_per_wg=to, k_groups=go, epilogue=P)
                 ops.fused_add_rms_norm_partial(self.part_o, go, resid, lw.post_norm, self.eps, x)
             else:
                 torch.mm(attn, lw.o_w.t(), out=o)
                 self._allreduce(o)
                 ops.fused_add_rms_norm(o, resid, lw.post_norm, self.eps, out=x)
-            self._linear_tiled(x, tw["gu"], 2 * self.F, out=act, tiles_per_wg=tg, epilogue=ops.EPI_SILU_MUL)
-            self._linear_tiled(act, tw["down"], self.H, partial=self.part_dn, tiles_per_wg=td, k_groups=gd, epilogue=P)
-        ops.fused_add_rms_norm_partial(self.part_dn, gd, resid, self.w.final_norm, self.eps, x)
+            if mode["gu"]:
+                self._linear_tiled(x, tw["gu"], 2 * self.F, out=act, tiles_per_wg=tg, epilogue=ops.EPI_SILU_MUL)
+            else:
+                torch.mm(x, lw.gate_up_w.t(), out=gu)
+                ops.silu_and_mul(gu, out=act)
+            if mode["down"]:
+                self._linear_tiled(act, tw["down"], self.H, partial=self.part_dn, tiles_per_wg=td, k_groups=gd,
+                                   epilogue=P)
+            else:
+                torch.mm(act, lw.down_w.t(), out=dn)
+                if self.mlp_sharded:
+                    self._allreduce(dn)
+        add_mlp_and_norm(self.w.final_norm)
 
     def lm_head_logits(self, x: torch.Tensor, out: torch.Tensor) -> None:
         """Decode-step logits of the rows in x."""
-        if self._use_tiled(x.shape[0]):
+        b = x.shape[0]
+        if self._mode(b)["lm_head"]:
             ops.linear_tiled(x, self.lm_head_tiled, self.V, out=out,
-                             tiles_per_wg=self._tiled_plan(x.shape[0])["lm_head"][0])
+                             tiles_per_wg=self._tiled_plan(self.bucket_for(b))["lm_head"][0])
         else:
             torch.mm(x, self.w.lm_head.t(), out=out)
 
@@ -278,6 +445,8 @@ class ModelRunner:
             torch.mm(x, lw.gate_up_w.t(), out=gu)
             ops.silu_and_mul(gu, out=act)
             torch.mm(act, lw.down_w.t(), out=dn)
+            if self.mlp_sharded:
+                self._allreduce(dn)
         return dn
 
     # ------------------------------------------------------------------ #
@@ -285,24 +454,9 @@ class ModelRunner:
     # ------------------------------------------------------------------ #
     def _decode_body(self, b: int) -> None:
         ids, pos, slots, ctx, bt = self.ids[:b], self.positions[:b], self.slots[:b], self.ctx[:b], self.block_tables[:b]
-        resid, x, qkv, attn = self.resid[:b], self.x[:b], self.qkv[:b], self.attn[:b]
-        o, gu, act, dn = self.o[:b], self.gu[:b], self.act[:b], self.dn[:b]
-        splits = self._splits_for(b)
-        torch.index_select(self.w.embed, 0, ids, out=resid)
-        if self._use_tiled(b):
-            self._decode_layers_tiled(b, pos, slots, bt, ctx, splits)
-            self.lm_head_logits(x, self.logits[:b])
-            ops.argmax(self.logits[:b], out=self.next_ids[:b])
-            return
-
-        def attend(i, qkv_, attn_):
-            ops.paged_attn_decode_fused(qkv_, self.cos_sin, slots, self.k_cache[i], self.v_cache[i], bt, ctx,
-                                        self.nh, self.nkv, self.d, self.scale, num_splits=splits,
-                                        workspace=self.attn_ws, out=attn_)
-
-        last = self._layers(b, resid, x, qkv, attn, o, gu, act, dn, attend)
-        ops.fused_add_rms_norm(last, resid, self.w.final_norm, self.eps, out=x)
-        self.lm_head_logits(x, self.logits[:b])
+        torch.index_select(self.w.embed, 0, ids, out=self.resid[:b])
+        self._decode_layers(b, slots, bt, ctx, self._splits_for(b))
+        self.lm_head_logits(self.x[:b], self.logits[:b])
         ops.argmax(self.logits[:b], out=self.next_ids[:b])
 
     def bucket_for(self, batch: int) -> int:
@@ -321,6 +475,7 @@ class ModelRunner:
         self.slots.fill_(-1)
         self.ctx.zero_()
         try:
+            self.tune(bucket)
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -344,10 +499,12 @@ class ModelRunner:
         buffers (ids, positions, slots, ctx, block_tables must be filled; rows
         beyond `batch` up to the bucket size must be neutral: slot -1, ctx 0).
         Returns a view of the sampled (greedy) token ids, on the device."""
+        bucket = self.bucket_for(batch)
         if not self.use_graphs:
+            if bucket not in self._modes:
+                self.tune(bucket)                         # scratch activations only: staged inputs are untouched
             self._decode_body(batch)
             return self.next_ids[:batch]
-        bucket = self.bucket_for(batch)
         if bucket not in self.graphs:
             try:
                 self.capture(bucket)

@@ -382,9 +382,10 @@ def plan_linear_tiled(N: int, K: int, split_k: bool, M: int = 32):
         wgs = -(-tiles_total // (tiles % 100))
         groups = 1
         if split_k and wgs < 160:
-            groups = max(1, min(-(-192 // wgs), units, 16))
+            # at most 8 slabs: the consumers (attention, norm) sum up to 8 with straight-line loads
+            groups = max(1, min(-(-192 // wgs), units, 8))
             # an even deal of the slices if one is near; otherwise K just does not divide evenly
-            for g in range(groups, min(2 * groups, units, 16) + 1):
+            for g in range(groups, min(2 * groups, units, 8) + 1):
                 if units % g == 0:
                     groups = g
                     break

@@ -3,9 +3,11 @@
 Per layer the q/k/v projections are concatenated into one [ (nh + 2*nkv) * d, H ]
 matrix and gate/up into one [2F, H] matrix, all row-major [out, in] in the model
 dtype.  Under tensor parallelism (one process per GPU) rank r keeps query heads
-[r*nh/P, (r+1)*nh/P), the matching kv heads, the matching COLUMNS of o_proj
-(row-parallel: partial sums are all-reduced), and full copies of the MLP, the
-embeddings and lm_head.
+[r*nh/P, (r+1)*nh/P), the matching kv heads and the matching COLUMNS of o_proj
+(row-parallel: partial sums are all-reduced).  With ``shard_mlp`` it also keeps
+only rows [r*F/P, (r+1)*F/P) of gate_proj and up_proj and the matching columns of
+down_proj (a second all-reduce per layer); otherwise the MLP is replicated.  The
+embeddings and lm_head are always replicated.
 
 Sources: a local HF directory with *.safetensors (the harness serves models
 from a local path, benchmark-mlflow/vllm_processor.py:29), an in-memory state
@@ -67,10 +69,19 @@ def _shard_heads(cfg: ModelConfig, tp_rank: int, tp_size: int):
         slice(tp_rank * nkv_l * cfg.head_dim, (tp_rank + 1) * nkv_l * cfg.head_dim)
 
 
+def _shard_mlp(cfg: ModelConfig, tp_rank: int, tp_size: int) -> slice:
+    F = cfg.intermediate_size
+    if F % tp_size:
+        raise ValueError(f"tensor_parallel_size {tp_size} must divide intermediate_size {F}")
+    return slice(tp_rank * (F // tp_size), (tp_rank + 1) * (F // tp_size))
+
+
 def from_getter(cfg: ModelConfig, get: Callable[[str], torch.Tensor], dtype: torch.dtype, device,
-                tp_rank: int = 0, tp_size: int = 1, num_layers: Optional[int] = None) -> ModelWeights:
+                tp_rank: int = 0, tp_size: int = 1, num_layers: Optional[int] = None,
+                shard_mlp: bool = False) -> ModelWeights:
     """``get(name)`` returns the full (unsharded) CPU tensor of an HF parameter."""
     _, _, qs, ks = _shard_heads(cfg, tp_rank, tp_size)
+    fs = _shard_mlp(cfg, tp_rank, tp_size) if shard_mlp else slice(None)
 
     def put(t: torch.Tensor) -> torch.Tensor:
         return t.to(dtype).contiguous().to(device)
@@ -86,10 +97,10 @@ def from_getter(cfg: ModelConfig, get: Callable[[str], torch.Tensor], dtype: tor
             qb, kb, vb = (get(p + f"self_attn.{n}_proj.bias") for n in "qkv")
             qkv_b = put(torch.cat([qb[qs], kb[ks], vb[ks]], dim=0))
         o = get(p + "self_attn.o_proj.weight")[:, qs]
-        gu = torch.cat([get(p + "mlp.gate_proj.weight"), get(p + "mlp.up_proj.weight")], dim=0)
+        gu = torch.cat([get(p + "mlp.gate_proj.weight")[fs], get(p + "mlp.up_proj.weight")[fs]], dim=0)
         w.layers.append(LayerWeights(
             qkv_w=put(qkv_w), qkv_b=qkv_b, o_w=put(o), gate_up_w=put(gu),
-            down_w=put(get(p + "mlp.down_proj.weight")),
+            down_w=put(get(p + "mlp.down_proj.weight")[:, fs]),
             input_norm=put(get(p + "input_layernorm.weight")),
             post_norm=put(get(p + "post_attention_layernorm.weight"))))
     w.final_norm = put(get("model.norm.weight"))
@@ -136,12 +147,15 @@ def from_safetensors(cfg, model_dir: str, dtype, device, **kw) -> ModelWeights:
 
 
 def synthetic(cfg: ModelConfig, dtype, device, seed: int = 0, tp_rank: int = 0, tp_size: int = 1,
-              num_layers: Optional[int] = None, std: float = 0.02) -> ModelWeights:
+              num_layers: Optional[int] = None, std: float = 0.02, shard_mlp: bool = False) -> ModelWeights:
     """Seeded N(0, std^2) matrices of the real shapes, generated on the device
     (an 8B model is 15 GB: too slow to draw on the host).  Every rank draws the
     replicated tensors from the same stream so they are bit-identical across ranks."""
     nh_l, nkv_l, _, _ = _shard_heads(cfg, tp_rank, tp_size)
     H, F, V, d = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.head_dim
+    if shard_mlp:
+        fs = _shard_mlp(cfg, tp_rank, tp_size)
+        F = fs.stop - fs.start
     shared = torch.Generator(device=device).manual_seed(seed)
     local = torch.Generator(device=device).manual_seed(seed * 1000003 + 17 + tp_rank)
 
@@ -155,8 +169,8 @@ def synthetic(cfg: ModelConfig, dtype, device, seed: int = 0, tp_rank: int = 0, 
             qkv_w=mat(local, (nh_l + 2 * nkv_l) * d, H),
             qkv_b=mat(local, (nh_l + 2 * nkv_l) * d) if cfg.attention_bias else None,
             o_w=mat(local, H, nh_l * d),
-            gate_up_w=mat(shared, 2 * F, H),
-            down_w=mat(shared, H, F),
+            gate_up_w=mat(local if shard_mlp else shared, 2 * F, H),
+            down_w=mat(local if shard_mlp else shared, H, F),
             input_norm=torch.ones(H, dtype=dtype, device=device),
             post_norm=torch.ones(H, dtype=dtype, device=device)))
     w.final_norm = torch.ones(H, dtype=dtype, device=device)
