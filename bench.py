@@ -61,9 +61,9 @@ def parse():
     return ap.parse_args()
 
 
-def model_bytes(cfg, tp, batch, mean_ctx, elem=2, layer_w_elem=None, mlp_tp=1):
+def model_bytes(cfg, tp, batch, mean_ctx, elem=2, layer_w_elem=None, mlp_tp=1, vocab_tp=1):
     """Algorithmic HBM bytes of one decode step per GPU: every weight once
-    (attention projections sharded over tp, the MLP over mlp_tp, lm_head replicated),
+    (attention projections sharded over tp, the MLP over mlp_tp, lm_head over vocab_tp),
     the K/V pages of the mean context, the new K/V rows, and the logits."""
     H, F, V, L, d = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.num_hidden_layers, cfg.head_dim
     nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
@@ -72,9 +72,9 @@ def model_bytes(cfg, tp, batch, mean_ctx, elem=2, layer_w_elem=None, mlp_tp=1):
     norms = 2 * H
     lw = elem if layer_w_elem is None else layer_w_elem      # fp8: 1 byte per layer weight + fp32 row scales
     rows = ((nh + 2 * nkv) * d + H) // tp + 2 * F // mlp_tp + H
-    w_bytes = L * ((attn_w + mlp_w) * lw + norms * elem + (rows * 4 if lw != elem else 0)) + (V * H + H) * elem
+    w_bytes = L * ((attn_w + mlp_w) * lw + norms * elem + (rows * 4 if lw != elem else 0)) + (V // vocab_tp * H + H) * elem
     kv_tok = 2 * (nkv // tp) * d * elem * L
-    return w_bytes + batch * mean_ctx * kv_tok + batch * kv_tok + batch * V * elem, w_bytes
+    return w_bytes + batch * mean_ctx * kv_tok + batch * kv_tok + batch * V // vocab_tp * elem, w_bytes
 
 
 def make_prompts(vocab, batch, plen, seed):
@@ -164,7 +164,7 @@ def time_kernels(engine, batch, ctx_len):
     else:
         out["gemm_o"] = timed(lambda i: torch.mm(attn, W[i].o_w.t(), out=o), gemm(b, r.H, r.nh * r.d, w_es=es))
     lm = r.w.lm_head
-    out["gemm_lm_head"] = timed(lambda i: r.lm_head_logits(x, r.logits[:b]), gemm(b, r.V, r.H, w_es=es))
+    out["gemm_lm_head"] = timed(lambda i: r.lm_head_logits(x, r.logits[:b]), gemm(b, r.Vl, r.H, w_es=es))
 
     # attention over the live cache, at the context lengths of the last timed step
     splits = r._splits_for(b)
@@ -192,7 +192,7 @@ def time_kernels(engine, batch, ctx_len):
                                                   num_splits=splits, workspace=r.attn_ws, out=attn),
             kv_bytes + rope_bytes)
     out["paged_attn_decode_fused"]["splits"] = splits
-    out["argmax"] = timed(lambda i: ops.argmax(r.logits[:b], out=r.next_ids[:b]), b * r.V * es)
+    out["argmax"] = timed(lambda i: ops.argmax(r.logits[:b], out=r.next_ids[:b]), b * r.Vl * es)
     return out
 
 
@@ -362,12 +362,13 @@ def main():
 
     lwe = 1 if a.quantization == "fp8" else None
     mlp_tp = tp if engine.runner.mlp_sharded else 1
-    step_bytes, w_bytes = model_bytes(cfg, tp, batch, mean_ctx, layer_w_elem=lwe, mlp_tp=mlp_tp)
+    vocab_tp = tp if engine.runner.vocab_sharded else 1
+    step_bytes, w_bytes = model_bytes(cfg, tp, batch, mean_ctx, layer_w_elem=lwe, mlp_tp=mlp_tp, vocab_tp=vocab_tp)
     if a.layers:
         import copy
         c2 = copy.copy(cfg)
         c2.num_hidden_layers = a.layers
-        step_bytes, w_bytes = model_bytes(c2, tp, batch, mean_ctx, layer_w_elem=lwe, mlp_tp=mlp_tp)
+        step_bytes, w_bytes = model_bytes(c2, tp, batch, mean_ctx, layer_w_elem=lwe, mlp_tp=mlp_tp, vocab_tp=vocab_tp)
     step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
 
     result = {
@@ -379,7 +380,8 @@ def main():
                                f"synthetic weights and token-id prompts; BASELINE.json configs[{1 if a.gpus == 1 else 2}]",
                    "global_batch": batch, "prompt_len": P, "gen_len": G,
                    "parallelism": (f"tp{tp} (attention heads and MLP sharded, two all-reduces per layer; lm_head "
-                                   f"replicated)" if mlp_tp > 1 else
+                                   + ("sharded over the vocabulary, greedy keys max-reduced)" if vocab_tp > 1 else "replicated)")
+                                   if mlp_tp > 1 else
                                    f"tp{tp} (attention heads sharded, MLP+lm_head replicated)") if tp > 1 else "tp1",
                    "mean_context": round(mean_ctx, 1), "hip_graphs": not a.eager},
         "ttft_ms_p50": round(ttft_ms, 2),

@@ -213,6 +213,26 @@ int32_t mi355_argmax(int64_t* out_ids, const void* logits,
                      int32_t logits_dtype, void* stream);
 
 /*
+ * Greedy sampling over a vocabulary that is split across tensor-parallel ranks
+ * (--tensor-parallel-size > 1, benchmark-vllm/vllm_templates.py:102-103): each
+ * rank holds the logits of vocabulary rows [index_offset, index_offset + vocab).
+ * out_keys[b] = the 64-bit key of the rank's best token,
+ *     ((order-preserving image of the logit) << 32 | (0xFFFFFFFF - global index))
+ *     XOR 0x8000000000000000,
+ * so that a SIGNED 64-bit max over the ranks' keys (one all-reduce of num_rows
+ * integers instead of a gather of the logits) is the key of the global argmax
+ * with mi355_argmax's semantics (lowest index on ties, NaN as the maximum);
+ * mi355_argmax_key_to_index turns the reduced keys into token ids.
+ */
+int32_t mi355_argmax_shard_key(int64_t* out_keys, const void* logits,
+                               int64_t logits_stride, int32_t num_rows,
+                               int32_t vocab, int32_t logits_dtype,
+                               int64_t index_offset, void* stream);
+
+int32_t mi355_argmax_key_to_index(int64_t* out_ids, const int64_t* keys,
+                                  int32_t num_rows, void* stream);
+
+/*
  * Random sampling with temperature, top-k and top-p, one row per sequence.
  * Candidates = the k highest logits (k = top_k[b] if 0 < top_k[b] <= 1024, else
  * 1024; ties at the threshold by lowest index) ordered by (logit desc, index

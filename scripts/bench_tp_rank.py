@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One GPU: the decode step of ONE tensor-parallel rank at the shapes of N-GPU runs (collectives
-replaced by no-ops), MLP sharded vs replicated, tiled vs library GEMMs vs the timing-based choice.  It prices the compute
+replaced by no-ops), MLP + lm_head sharded vs replicated, tiled vs library GEMMs vs the timing-based choice.  It prices the compute
 side of a rank's step; the all-reduces come on top on a real node.
 
     python scripts/bench_tp_rank.py [--model llama-3-8b] [--tps 2,4,8] [--batch-per-gpu 32]
@@ -25,10 +25,11 @@ def step_ms(cfg, tp, batch, ctx, shard_mlp, tiled, layers):
     max_len = ctx + 64
     bps = (max_len + 15) // 16
     ws = W.synthetic(cfg, torch.bfloat16, "cuda", seed=1, tp_rank=tp - 1, tp_size=tp, num_layers=layers,
-                     shard_mlp=shard_mlp)
+                     shard_mlp=shard_mlp, shard_vocab=shard_mlp)
     r = ModelRunner(cfg, ws, torch.bfloat16, "cuda", num_blocks=batch * bps, max_num_seqs=batch, max_model_len=max_len,
                     tp_rank=tp - 1, tp_size=tp, tp_group=None, tiled_linears=tiled)
     r._allreduce = lambda t: None
+    r._allreduce_max = lambda t: None
     n64, n32 = r.host_inputs()
     B = batch
     n64[:B] = np.arange(B) + 1000
@@ -72,7 +73,7 @@ def main():
                 ms, used, tuned = step_ms(cfg, tp, batch, a.ctx, shard, tiled, L)
                 if tiled is not False and used == "-----":
                     continue                              # no tiled kernels for this row count: same as library
-                print(json.dumps({"model": a.model, "tp": tp, "batch": batch, "layers": L, "mlp_sharded": shard,
+                print(json.dumps({"model": a.model, "tp": tp, "batch": batch, "layers": L, "mlp_and_vocab_sharded": shard,
                                   "gemms": {True: "tiled", False: "library", None: "timed choice"}[tiled],
                                   "tiled_projections": used, "rank_step_ms": round(ms, 4),
                                   "tok_s_without_collectives": round(batch / ms * 1e3, 1),

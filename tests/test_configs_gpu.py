@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 CASES = [
-    # name, model, tp, rank, batch, context, max_model_len, MLP sharded over the ranks
+    # name, model, tp, rank, batch, context, max_model_len, MLP and lm_head sharded over the ranks
     ("cfg1", "llama-3-8b", 1, 0, 32, 200, 256, False),
     ("cfg2", "llama-3-8b", 4, 2, 128, 200, 256, False),
     ("cfg2_mlp_sharded", "llama-3-8b", 4, 2, 128, 200, 256, True),
@@ -37,11 +37,12 @@ def test_rank_decode_step_tiled_vs_library(case, monkeypatch):
     out = {}
     for tiled in (True, False):
         ws = W.synthetic(cfg, torch.bfloat16, "cuda", seed=5, tp_rank=rank, tp_size=tp, num_layers=2, std=0.03,
-                         shard_mlp=shard_mlp)
+                         shard_mlp=shard_mlp, shard_vocab=shard_mlp)
         r = ModelRunner(cfg, ws, torch.bfloat16, "cuda", num_blocks=batch * blocks_per_seq, max_num_seqs=batch,
                         max_model_len=max_len, tp_rank=rank, tp_size=tp, tp_group=None, tiled_linears=tiled)
         monkeypatch.setattr(r, "_allreduce", lambda t: None)      # this rank's share only
-        assert r._use_tiled(r.bucket_for(batch)) == tiled and r.mlp_sharded == shard_mlp
+        monkeypatch.setattr(r, "_allreduce_max", lambda t: None)  # ... and the best token of its vocabulary slice
+        assert r._use_tiled(r.bucket_for(batch)) == tiled and r.mlp_sharded == shard_mlp == r.vocab_sharded
         g = torch.Generator(device="cuda").manual_seed(11)
         for kc, vc in zip(r.k_cache, r.v_cache):
             kc.normal_(0, 1.0, generator=g)
@@ -60,6 +61,9 @@ def test_rank_decode_step_tiled_vs_library(case, monkeypatch):
         del r, ws
         torch.cuda.empty_cache()
     (lt, tt), (ll, tl) = out[True], out[False]
+    if shard_mlp:                                              # tokens of this rank's slice carry their global ids
+        V = cfg.vocab_size // tp
+        assert lt.shape[1] == V and (tt >= rank * V).all() and (tt < (rank + 1) * V).all()
     assert np.isfinite(lt).all() and np.isfinite(ll).all()
     scale = np.abs(ll).max()
     err = np.abs(lt - ll)

@@ -353,6 +353,37 @@ def test_argmax(ops, ldt, B, V):
     np.testing.assert_array_equal(out.cpu().numpy(), ref)  # bit-exact indices
 
 
+@pytest.mark.parametrize("ldt", ["bfloat16", "float16", "float32"])
+@pytest.mark.parametrize("B,V,shards", [(5, 512, 2), (32, 128256, 8), (3, 448, 4), (1, 16, 1)])
+def test_argmax_over_vocabulary_shards(ops, ops_golden, ldt, B, V, shards):
+    """Greedy sampling with the vocabulary split over ranks: every shard's key equals the oracle's
+    bit for bit, and the signed max of the shards' keys decodes to the argmax of the whole row
+    (ties across shards -> lowest global index, NaN on top, signed zeros equal)."""
+    rng = rng_for("argmax-shards", ldt, B, V)
+    lg = R.round_to((rng.standard_normal((B, V)) * 4).astype(np.float32), ldt)
+    hi = 64.0                                            # above every drawn logit, exact in all three types
+    Vs = V // shards
+    if shards > 1:
+        lg[0, [Vs - 1, Vs + 2, V - 1]] = hi              # the same maximum in two shards
+        lg[B - 1, :] = -0.0
+        lg[B - 1, V - 2] = 0.0                           # all equal: index 0 of shard 0
+        if B > 2:
+            lg[1, Vs + 3] = np.nan                       # NaN beats everything
+            lg[1, 0] = hi
+    tdt = {"float32": torch.float32, **DT}[ldt]
+    full = torch.from_numpy(lg).to(tdt).cuda()
+    keys = []
+    for r in range(shards):
+        k = ops.argmax_shard_key(full[:, r * Vs:(r + 1) * Vs].contiguous(), r * Vs)
+        np.testing.assert_array_equal(k.cpu().numpy(), R.argmax_shard_key(lg[:, r * Vs:(r + 1) * Vs], r * Vs))
+        keys.append(k)
+    best = torch.stack(keys).max(dim=0).values           # what the all-reduce(MAX) over ranks computes
+    ids = ops.argmax_key_to_index(best).cpu().numpy()
+    np.testing.assert_array_equal(ids, R.argmax_key_to_index(best.cpu().numpy()))
+    np.testing.assert_array_equal(ids, R.argmax_lowest(lg))
+    np.testing.assert_array_equal(ids, ops.argmax(full).cpu().numpy())
+
+
 def test_argmax_golden_and_nan(ops, ops_golden):
     lg = ops_golden["argmax_logits"]
     out = ops.argmax(torch.from_numpy(lg).cuda())

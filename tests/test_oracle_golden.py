@@ -104,6 +104,20 @@ def test_argmax(ops_golden):
     np.testing.assert_array_equal(R.argmax_lowest(ops_golden["argmax_logits"]), ops_golden["argmax_idx"])
 
 
+def test_argmax_shard_keys_reduce_to_the_golden_argmax(ops_golden):
+    """The vocabulary-parallel form (one key per shard, signed max, decode) gives the committed
+    argmax indices for every way of cutting the golden rows into equal shards."""
+    lg = ops_golden["argmax_logits"]
+    V = lg.shape[1]
+    for shards in (1, 2, 4, 8):
+        if V % shards:
+            continue
+        Vs = V // shards
+        keys = np.stack([R.argmax_shard_key(lg[:, r * Vs:(r + 1) * Vs], r * Vs) for r in range(shards)])
+        assert keys.dtype == np.int64
+        np.testing.assert_array_equal(R.argmax_key_to_index(keys.max(axis=0)), ops_golden["argmax_idx"])
+
+
 def test_round_to_bits_roundtrip():
     rng = np.random.Generator(np.random.PCG64(5))
     x = rng.standard_normal(1000).astype(np.float32) * 100

@@ -75,6 +75,16 @@ def _shard_worker(rank, world, port, q):
         part = mlp(sw, Fl)
         dist.all_reduce(part)
         assert torch.allclose(part, mlp(fw, F), atol=1e-4)
+        # vocabulary-parallel lm_head: each rank's best-token key, max-reduced, is the global argmax
+        from oracle import ops_ref as R
+        vw = W.from_state_dict(mc, sd, torch.float32, "cpu", tp_rank=rank, tp_size=world, shard_vocab=True)
+        Vl = mc.vocab_size // world
+        assert vw.lm_head.shape == (Vl, H) and torch.equal(vw.lm_head, full.lm_head[rank * Vl:(rank + 1) * Vl])
+        logits_full = (x @ full.lm_head.t()).numpy()
+        logits_full[0, [3, Vl + 1]] = logits_full.max() + 1.0            # a tie across the two slices
+        keys = torch.from_numpy(R.argmax_shard_key(logits_full[:, rank * Vl:(rank + 1) * Vl], rank * Vl))
+        dist.all_reduce(keys, op=dist.ReduceOp.MAX)
+        assert np.array_equal(R.argmax_key_to_index(keys.numpy()), R.argmax_lowest(logits_full))
         q.put((rank, "ok"))
     except Exception as exc:  # noqa: BLE001
         q.put((rank, repr(exc)))

@@ -1,7 +1,8 @@
 """Tensor parallelism end to end on ONE GPU: two engine processes (rank 0 and 1 of a
 TP=2 group) share the card and exchange their partial sums over gloo -- RCCL refuses two
 ranks on one device, and gloo cannot be graph-captured, so the steps run eagerly.  What is
-pinned: the head and MLP sharding of the weights, both all-reduce call sites, the
+pinned: the head, MLP and vocabulary sharding of the weights, both all-reduce call sites,
+the key max-reduce of greedy sampling and the gather of whole rows for random sampling, the
 lock-step of the two schedulers, and the generated tokens against the numpy oracle of the
 unsharded model (a sharded sum rounds differently: a sequence may leave the oracle at a
 near-tie of the oracle's own logits, as in test_model_gpu)."""
@@ -33,14 +34,15 @@ def _worker(rank, world, port, name, dtype, shard_mlp, q):
             if p not in sys.path:
                 sys.path.insert(0, p)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                          LOCAL_RANK="0", MI355_DIST_BACKEND="gloo", MI355_TP_MLP="1" if shard_mlp else "0")
+                          LOCAL_RANK="0", MI355_DIST_BACKEND="gloo", MI355_TP_MLP="1" if shard_mlp else "0",
+                          MI355_TP_VOCAB="1" if shard_mlp else "0")
         import torch
         import torch.distributed as dist
         from test_model_gpu import build, engine_generate
         from oracle.tiny_models import make_prompts
         eng, cfg, w = build(name, dtype, tensor_parallel_size=world, enforce_eager=True)
         r = eng.runner
-        assert r.tp_size == world and r.mlp_sharded == shard_mlp
+        assert r.tp_size == world and r.mlp_sharded == shard_mlp == r.vocab_sharded
         assert r.F * (world if shard_mlp else 1) == cfg["intermediate_size"]
         calls = [0]
         inner = r._allreduce
@@ -53,7 +55,24 @@ def _worker(rank, world, port, name, dtype, shard_mlp, q):
         steps = eng.stats["decode_steps"] + eng.stats["prefill_steps"]
         per_step = r.L * (2 if shard_mlp else 1)               # a step launched ahead may not be counted yet
         assert calls[0] % per_step == 0 and calls[0] >= steps * per_step, (calls[0], steps)
-        q.put((rank, "ok", toks.tolist()))
+        # random sampling and log-probabilities need whole rows: gathered from the ranks' slices
+        from mi355_decode.sampling_params import SamplingParams
+        sampled = {}
+        for i, p in enumerate(make_prompts(name, 3, [7, 19, 30])):
+            eng.add_request(f"s{i}", [int(t) for t in p], SamplingParams(max_tokens=6, temperature=0.8, top_k=20,
+                                                                       top_p=0.9, seed=5 + i, logprobs=2,
+                                                                       ignore_eos=True))
+            sampled[f"s{i}"] = ([], [])
+        while eng.has_unfinished():
+            for o in eng.step():
+                sampled[o.request_id][0].extend(o.new_token_ids)
+                sampled[o.request_id][1].extend(o.logprobs or [])
+        for ids, lps in sampled.values():
+            assert len(ids) == 6 and len(lps) == 6
+            for tok, (lp, top) in zip(ids, lps):
+                assert lp <= 0.0 and len(top) == 2 and top[0][1] >= top[1][1] and top[0][1] >= lp - 1e-6
+                assert 0 <= tok < cfg["vocab_size"] and all(0 <= t < cfg["vocab_size"] for t, _ in top)
+        q.put((rank, "ok", [toks.tolist(), {k: [v[0], [[lp, top] for lp, top in v[1]]] for k, v in sampled.items()}]))
         dist.barrier()
     except Exception:  # noqa: BLE001
         import traceback
@@ -86,8 +105,9 @@ def test_two_ranks_generate_like_the_unsharded_oracle(name, dtype, shard_mlp):
                 p.kill()
     for rank, msg, _ in res:
         assert msg == "ok", f"rank {rank}: {msg}"
-    t0, t1 = np.array(res[0][2]), np.array(res[1][2])
+    t0, t1 = np.array(res[0][2][0]), np.array(res[1][2][0])
     assert np.array_equal(t0, t1), "the two ranks sampled different tokens"
+    assert res[0][2][1] == res[1][2][1], "the two ranks drew different random samples or log-probabilities"
     _, cfg, w = make_weights(name)
     w = {k: R.round_to(v, dtype) for k, v in w.items()}
     ref_tokens, ref_logits = oracle_run(cfg, w, dtype, make_prompts(name, len(LENGTHS), LENGTHS), GEN)

@@ -29,10 +29,13 @@ __device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsig
   return a > b ? a : b;
 }
 
-template <int LDT>
+// KEYED: out[row] is the row's best key itself, with the index moved by index_offset (the
+// position of this slice of the vocabulary in the whole one) and the top bit flipped so that
+// SIGNED 64-bit max over the slices' keys orders them as the unsigned keys do.
+template <int LDT, bool KEYED>
 __global__ __launch_bounds__(kArgmaxThreads) void argmax_kernel(int64_t* __restrict__ out,
                                                                 const void* __restrict__ logits,
-                                                                int64_t stride, int vocab) {
+                                                                int64_t stride, int vocab, uint32_t index_offset) {
   const int row = blockIdx.x;
   unsigned long long best = 0ull;
   if (LDT == MI355_F32) {
@@ -71,8 +74,20 @@ __global__ __launch_bounds__(kArgmaxThreads) void argmax_kernel(int64_t* __restr
     unsigned long long b = part[0];
 #pragma unroll
     for (int i = 1; i < kArgmaxThreads / 64; ++i) b = umax64(b, part[i]);
-    out[row] = static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(b & 0xFFFFFFFFull));
+    const uint32_t idx = 0xFFFFFFFFu - static_cast<uint32_t>(b & 0xFFFFFFFFull);
+    if (KEYED) {
+      const unsigned long long moved = (b & 0xFFFFFFFF00000000ull) |
+                                       static_cast<unsigned long long>(0xFFFFFFFFu - (idx + index_offset));
+      out[row] = static_cast<int64_t>(moved ^ 0x8000000000000000ull);
+    } else {
+      out[row] = static_cast<int64_t>(idx);
+    }
   }
+}
+
+__global__ void argmax_key_to_index_kernel(int64_t* __restrict__ out, const int64_t* __restrict__ keys, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(static_cast<unsigned long long>(keys[i]) & 0xFFFFFFFFull));
 }
 
 
@@ -298,12 +313,14 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
 
 }  // namespace mi355
 
-extern "C" int32_t mi355_argmax(int64_t* out_ids, const void* logits, int64_t logits_stride,
-                                int32_t num_rows, int32_t vocab, int32_t logits_dtype, void* stream) {
-  using namespace mi355;
-  const char* name = "mi355_argmax";
-  MI355_REQUIRE(out_ids && logits, MI355_ERR_INVALID, "%s: null pointer", name);
+namespace mi355 {
+static int32_t argmax_entry(const char* name, int64_t* out, const void* logits, int64_t logits_stride,
+                            int32_t num_rows, int32_t vocab, int32_t logits_dtype, bool keyed, int64_t index_offset,
+                            void* stream) {
+  MI355_REQUIRE(out && logits, MI355_ERR_INVALID, "%s: null pointer", name);
   MI355_REQUIRE(num_rows >= 0 && vocab > 0, MI355_ERR_INVALID, "%s: num_rows/vocab out of range", name);
+  MI355_REQUIRE(index_offset >= 0 && index_offset + vocab <= 0xFFFFFFFFll, MI355_ERR_INVALID,
+                "%s: index_offset + vocab must fit 32 bits", name);
   MI355_REQUIRE(logits_dtype == MI355_BF16 || logits_dtype == MI355_F16 || logits_dtype == MI355_F32,
                 MI355_ERR_UNSUPPORTED, "%s: logits dtype %d not supported", name, logits_dtype);
   const int per16 = logits_dtype == MI355_F32 ? 4 : 8;
@@ -313,12 +330,43 @@ extern "C" int32_t mi355_argmax(int64_t* out_ids, const void* logits, int64_t lo
   if (num_rows == 0) return MI355_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(num_rows), block(kArgmaxThreads);
-  if (logits_dtype == MI355_F32)
-    hipLaunchKernelGGL((argmax_kernel<MI355_F32>), grid, block, 0, s, out_ids, logits, logits_stride, vocab);
-  else if (logits_dtype == MI355_BF16)
-    hipLaunchKernelGGL((argmax_kernel<MI355_BF16>), grid, block, 0, s, out_ids, logits, logits_stride, vocab);
-  else
-    hipLaunchKernelGGL((argmax_kernel<MI355_F16>), grid, block, 0, s, out_ids, logits, logits_stride, vocab);
+  const uint32_t off = static_cast<uint32_t>(index_offset);
+#define MI355_ARGMAX(LDT)                                                                                         \
+  do {                                                                                                            \
+    if (keyed)                                                                                                    \
+      hipLaunchKernelGGL((argmax_kernel<LDT, true>), grid, block, 0, s, out, logits, logits_stride, vocab, off);  \
+    else                                                                                                          \
+      hipLaunchKernelGGL((argmax_kernel<LDT, false>), grid, block, 0, s, out, logits, logits_stride, vocab, off); \
+  } while (0)
+  if (logits_dtype == MI355_F32) MI355_ARGMAX(MI355_F32);
+  else if (logits_dtype == MI355_BF16) MI355_ARGMAX(MI355_BF16);
+  else MI355_ARGMAX(MI355_F16);
+#undef MI355_ARGMAX
+  return check_launch(name);
+}
+}  // namespace mi355
+
+extern "C" int32_t mi355_argmax(int64_t* out_ids, const void* logits, int64_t logits_stride,
+                                int32_t num_rows, int32_t vocab, int32_t logits_dtype, void* stream) {
+  return mi355::argmax_entry("mi355_argmax", out_ids, logits, logits_stride, num_rows, vocab, logits_dtype, false, 0,
+                             stream);
+}
+
+extern "C" int32_t mi355_argmax_shard_key(int64_t* out_keys, const void* logits, int64_t logits_stride,
+                                          int32_t num_rows, int32_t vocab, int32_t logits_dtype,
+                                          int64_t index_offset, void* stream) {
+  return mi355::argmax_entry("mi355_argmax_shard_key", out_keys, logits, logits_stride, num_rows, vocab, logits_dtype,
+                             true, index_offset, stream);
+}
+
+extern "C" int32_t mi355_argmax_key_to_index(int64_t* out_ids, const int64_t* keys, int32_t num_rows, void* stream) {
+  using namespace mi355;
+  const char* name = "mi355_argmax_key_to_index";
+  MI355_REQUIRE(out_ids && keys, MI355_ERR_INVALID, "%s: null pointer", name);
+  MI355_REQUIRE(num_rows >= 0, MI355_ERR_INVALID, "%s: num_rows out of range", name);
+  if (num_rows == 0) return MI355_OK;
+  hipLaunchKernelGGL(argmax_key_to_index_kernel, dim3((num_rows + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), out_ids, keys, num_rows);
   return check_launch(name);
 }
 

@@ -85,7 +85,9 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
     # MI355_TP_MLP=0 keeps the MLP replicated under tensor parallelism (one all-reduce per layer
     # instead of two, at N times the MLP weight bytes per GPU)
     shard_mlp = tp > 1 and os.environ.get("MI355_TP_MLP", "1") != "0" and cfg.intermediate_size % (32 * tp) == 0
-    kw = dict(tp_rank=rank, tp_size=tp, num_layers=nl, shard_mlp=shard_mlp)
+    # MI355_TP_VOCAB=0 keeps a full lm_head on every rank
+    shard_vocab = tp > 1 and os.environ.get("MI355_TP_VOCAB", "1") != "0" and cfg.vocab_size % (16 * tp) == 0
+    kw = dict(tp_rank=rank, tp_size=tp, num_layers=nl, shard_mlp=shard_mlp, shard_vocab=shard_vocab)
     if state_dict is not None:
         weights = W.from_state_dict(cfg, state_dict, dtype, device, **kw)
     elif args.load_format != "dummy" and W.has_checkpoint(args.model):

@@ -74,6 +74,13 @@ class ModelRunner:
         if self.mlp_sharded and self.F * tp_size != cfg.intermediate_size:
             raise ValueError(f"MLP slice of {self.F} columns does not match intermediate_size "
                              f"{cfg.intermediate_size} / tensor_parallel_size {tp_size}")
+        # ... and whether it holds the whole lm_head or the rows of its slice of the vocabulary
+        self.Vl = int(weights.lm_head.shape[0])
+        self.vocab_sharded = self.Vl != self.V
+        if self.vocab_sharded and self.Vl * tp_size != self.V:
+            raise ValueError(f"lm_head slice of {self.Vl} rows does not match vocab_size {self.V} / "
+                             f"tensor_parallel_size {tp_size}")
+        self.vocab_offset = tp_rank * self.Vl if self.vocab_sharded else 0
         self.L = len(weights.layers)
         self.qw = (self.nh + 2 * self.nkv) * self.d
         self.scale = self.d ** -0.5
@@ -117,8 +124,9 @@ class ModelRunner:
         self.gu = torch.zeros(B, 2 * self.F, **f)
         self.act = torch.zeros(B, self.F, **f)
         self.dn = torch.zeros(B, self.H, **f)
-        self.logits = torch.zeros(B, self.V, **f)
+        self.logits = torch.zeros(B, self.Vl, **f)          # this rank's slice of the vocabulary
         self.next_ids = torch.zeros(B, **i64)
+        self.keys = torch.zeros(B, **i64)
         self._max_splits = 16
         self.attn_ws = torch.empty(max(ops.decode_workspace_bytes(B, self.nh, self.d, self._max_splits), 16),
                                    dtype=torch.uint8, device=dev)
@@ -165,7 +173,7 @@ class ModelRunner:
         if self.tiled_policy == "off" or self.dtype not in (torch.bfloat16, torch.float16) or (2 * self.F) % 32:
             return
         self.tiled_shapes = {"qkv": (self.qw, self.H, True), "gu": (2 * self.F, self.H, False),
-                             "lm_head": (self.V, self.H, False)}
+                             "lm_head": (self.Vl, self.H, False)}
         if self.tp_size == 1:
             self.tiled_shapes["o"] = (self.H, self.nh * self.d, True)
         if not self.mlp_sharded:
@@ -312,7 +320,7 @@ class ModelRunner:
                                             ops.fused_add_rms_norm(dn, resid, W[i].input_norm, eps, out=x)))
             if "lm_head" in avail:
                 th = avail["lm_head"][0]
-                forms["lm_head"] = (lambda i: ops.linear_tiled(x, self.lm_head_tiled, self.V, out=self.logits[:b],
+                forms["lm_head"] = (lambda i: ops.linear_tiled(x, self.lm_head_tiled, self.Vl, out=self.logits[:b],
                                                                tiles_per_wg=th),
                                     lambda i: torch.mm(x, self.w.lm_head.t(), out=self.logits[:b]))
             self.tune_us = getattr(self, "tune_us", {})
@@ -405,10 +413,40 @@ class ModelRunner:
         """Decode-step logits of the rows in x."""
         b = x.shape[0]
         if self._mode(b)["lm_head"]:
-            ops.linear_tiled(x, self.lm_head_tiled, self.V, out=out,
+            ops.linear_tiled(x, self.lm_head_tiled, self.Vl, out=out,
                              tiles_per_wg=self._tiled_plan(self.bucket_for(b))["lm_head"][0])
         else:
             torch.mm(x, self.w.lm_head.t(), out=out)
+
+    def greedy(self, logits: torch.Tensor, out: torch.Tensor) -> None:
+        """Greedy token of every row.  With the vocabulary split over the ranks each rank reduces its
+        slice to one 64-bit (logit, global index) key per row and the keys are max-reduced: 8 bytes
+        per row cross the links instead of the logits, and the result equals the argmax over the
+        whole vocabulary (lowest index on ties) on every rank."""
+        if not self.vocab_sharded:
+            ops.argmax(logits, out=out)
+            return
+        keys = self.keys[: logits.shape[0]] if logits.shape[0] <= self.keys.numel() else \
+            torch.empty(logits.shape[0], dtype=torch.int64, device=self.device)
+        ops.argmax_shard_key(logits, self.vocab_offset, out=keys)
+        self._allreduce_max(keys)
+        ops.argmax_key_to_index(keys, out=out)
+
+    def _allreduce_max(self, t: torch.Tensor) -> None:
+        if self.tp_size > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.tp_group)
+
+    def full_logits(self, logits: torch.Tensor) -> torch.Tensor:
+        """[rows, vocab_size] logits from this rank's slice (sampling and log-probabilities need the
+        whole row; greedy steps never gather)."""
+        if not self.vocab_sharded:
+            return logits
+        parts = [torch.empty_like(logits, memory_format=torch.contiguous_format) for _ in range(self.tp_size)]
+        self._allgather(parts, logits.contiguous())
+        return torch.cat(parts, dim=1)
+
+    def _allgather(self, parts, t: torch.Tensor) -> None:
+        torch.distributed.all_gather(parts, t, group=self.tp_group)
 
     def kv_cache_bytes_per_block(self) -> int:
         return 2 * self.L * self.nkv * BLOCK_SIZE * self.d * self.k_cache[0].element_size()
@@ -457,7 +495,7 @@ class ModelRunner:
         torch.index_select(self.w.embed, 0, ids, out=self.resid[:b])
         self._decode_layers(b, slots, bt, ctx, self._splits_for(b))
         self.lm_head_logits(self.x[:b], self.logits[:b])
-        ops.argmax(self.logits[:b], out=self.next_ids[:b])
+        self.greedy(self.logits[:b], self.next_ids[:b])
 
     def bucket_for(self, batch: int) -> int:
         for s in self.buckets:
@@ -568,11 +606,13 @@ class ModelRunner:
             self.in64.copy_(self.h64s[stage], non_blocking=True)
         self.in32.copy_(self.h32s[stage], non_blocking=True)
         nxt = self.decode(batch)
+        if sampling is not None or logprobs >= 0:
+            logits = self.full_logits(self.logits[:batch])
         if sampling is not None:
-            self._sample(self.logits[:batch], sampling, nxt)
+            self._sample(logits, sampling, nxt)
         self.h_nexts[stage][:batch].copy_(nxt, non_blocking=True)
         if logprobs >= 0:
-            self.h_lp[stage][:batch, : 1 + 2 * logprobs].copy_(self._logprobs(self.logits[:batch], nxt, logprobs),
+            self.h_lp[stage][:batch, : 1 + 2 * logprobs].copy_(self._logprobs(logits, nxt, logprobs),
                                                                non_blocking=True)
         self.done[stage].record()
 
@@ -644,5 +684,6 @@ class ModelRunner:
         xs = torch.empty_like(last_sel)
         ops.fused_add_rms_norm(last_sel, resid_sel, self.w.final_norm, self.eps, out=xs)
         logits = torch.mm(xs, self.w.lm_head.t())
-        nxt = ops.argmax(logits)
-        return nxt, (logits if want_logits else None)
+        nxt = torch.empty(logits.shape[0], dtype=torch.int64, device=self.device)
+        self.greedy(logits, nxt)
+        return nxt, (self.full_logits(logits) if want_logits else None)

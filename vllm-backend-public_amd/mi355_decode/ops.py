@@ -287,6 +287,31 @@ def argmax(logits: torch.Tensor, out: torch.Tensor | None = None):
     return out
 
 
+def argmax_shard_key(logits: torch.Tensor, index_offset: int, out: torch.Tensor | None = None):
+    """Key of the best token of a vocabulary slice whose first row is token `index_offset`:
+    a signed 64-bit max over the slices' keys is the key of the argmax of the whole vocabulary
+    (argmax_key_to_index turns it into the token id)."""
+    _dev(logits, "logits")
+    if logits.dtype not in _DT:
+        raise TypeError(f"logits dtype {logits.dtype} not supported")
+    B, V = logits.shape
+    if out is None:
+        out = torch.empty(B, dtype=torch.int64, device=logits.device)
+    check(lib.mi355_argmax_shard_key(out.data_ptr(), logits.data_ptr(), _rows(logits, "logits"), B, V,
+                                     _DT[logits.dtype], int(index_offset), _stream()))
+    return out
+
+
+def argmax_key_to_index(keys: torch.Tensor, out: torch.Tensor | None = None):
+    _dev(keys, "keys")
+    if keys.dtype != torch.int64 or not keys.is_contiguous():
+        raise TypeError("keys must be contiguous int64")
+    if out is None:
+        out = torch.empty_like(keys)
+    check(lib.mi355_argmax_key_to_index(out.data_ptr(), keys.data_ptr(), keys.numel(), _stream()))
+    return out
+
+
 LINEAR_DECODE_MAX_M = 128
 
 

@@ -6,8 +6,10 @@ dtype.  Under tensor parallelism (one process per GPU) rank r keeps query heads
 [r*nh/P, (r+1)*nh/P), the matching kv heads and the matching COLUMNS of o_proj
 (row-parallel: partial sums are all-reduced).  With ``shard_mlp`` it also keeps
 only rows [r*F/P, (r+1)*F/P) of gate_proj and up_proj and the matching columns of
-down_proj (a second all-reduce per layer); otherwise the MLP is replicated.  The
-embeddings and lm_head are always replicated.
+down_proj (a second all-reduce per layer); otherwise the MLP is replicated.  With
+``shard_vocab`` it keeps rows [r*V/P, (r+1)*V/P) of lm_head (greedy sampling then
+max-reduces one key per sequence; full rows are gathered only for random sampling
+and log-probabilities).  The embeddings are always replicated.
 
 Sources: a local HF directory with *.safetensors (the harness serves models
 from a local path, benchmark-mlflow/vllm_processor.py:29), an in-memory state
@@ -49,7 +51,7 @@ class ModelWeights:
 
     def nbytes(self) -> int:
         total = self.embed.numel() * self.embed.element_size()
-        if self.lm_head.data_ptr() != self.embed.data_ptr():
+        if self.lm_head.untyped_storage().data_ptr() != self.embed.untyped_storage().data_ptr():
             total += self.lm_head.numel() * self.lm_head.element_size()
         total += self.final_norm.numel() * self.final_norm.element_size()
         for lw in self.layers:
@@ -76,9 +78,16 @@ def _shard_mlp(cfg: ModelConfig, tp_rank: int, tp_size: int) -> slice:
     return slice(tp_rank * (F // tp_size), (tp_rank + 1) * (F // tp_size))
 
 
+def _shard_vocab(cfg: ModelConfig, tp_rank: int, tp_size: int) -> slice:
+    V = cfg.vocab_size
+    if V % (16 * tp_size):
+        raise ValueError(f"16 * tensor_parallel_size {tp_size} must divide vocab_size {V} to shard lm_head")
+    return slice(tp_rank * (V // tp_size), (tp_rank + 1) * (V // tp_size))
+
+
 def from_getter(cfg: ModelConfig, get: Callable[[str], torch.Tensor], dtype: torch.dtype, device,
                 tp_rank: int = 0, tp_size: int = 1, num_layers: Optional[int] = None,
-                shard_mlp: bool = False) -> ModelWeights:
+                shard_mlp: bool = False, shard_vocab: bool = False) -> ModelWeights:
     """``get(name)`` returns the full (unsharded) CPU tensor of an HF parameter."""
     _, _, qs, ks = _shard_heads(cfg, tp_rank, tp_size)
     fs = _shard_mlp(cfg, tp_rank, tp_size) if shard_mlp else slice(None)
@@ -104,7 +113,8 @@ def from_getter(cfg: ModelConfig, get: Callable[[str], torch.Tensor], dtype: tor
             input_norm=put(get(p + "input_layernorm.weight")),
             post_norm=put(get(p + "post_attention_layernorm.weight"))))
     w.final_norm = put(get("model.norm.weight"))
-    w.lm_head = w.embed if cfg.tie_word_embeddings else put(get("lm_head.weight"))
+    vs = _shard_vocab(cfg, tp_rank, tp_size) if shard_vocab else slice(None)
+    w.lm_head = w.embed[vs] if cfg.tie_word_embeddings else put(get("lm_head.weight")[vs])
     return w
 
 
@@ -147,7 +157,8 @@ def from_safetensors(cfg, model_dir: str, dtype, device, **kw) -> ModelWeights:
 
 
 def synthetic(cfg: ModelConfig, dtype, device, seed: int = 0, tp_rank: int = 0, tp_size: int = 1,
-              num_layers: Optional[int] = None, std: float = 0.02, shard_mlp: bool = False) -> ModelWeights:
+              num_layers: Optional[int] = None, std: float = 0.02, shard_mlp: bool = False,
+              shard_vocab: bool = False) -> ModelWeights:
     """Seeded N(0, std^2) matrices of the real shapes, generated on the device
     (an 8B model is 15 GB: too slow to draw on the host).  Every rank draws the
     replicated tensors from the same stream so they are bit-identical across ranks."""
@@ -174,5 +185,9 @@ def synthetic(cfg: ModelConfig, dtype, device, seed: int = 0, tp_rank: int = 0, 
             input_norm=torch.ones(H, dtype=dtype, device=device),
             post_norm=torch.ones(H, dtype=dtype, device=device)))
     w.final_norm = torch.ones(H, dtype=dtype, device=device)
-    w.lm_head = w.embed if cfg.tie_word_embeddings else mat(shared, V, H)
+    if shard_vocab:
+        vs = _shard_vocab(cfg, tp_rank, tp_size)
+        w.lm_head = w.embed[vs] if cfg.tie_word_embeddings else mat(local, vs.stop - vs.start, H)
+    else:
+        w.lm_head = w.embed if cfg.tie_word_embeddings else mat(shared, V, H)
     return w
