@@ -96,7 +96,7 @@ class FakeRunner:
         return out
 
     def run_prefill(self, token_ids, positions, slot_mapping, block_tables, cu_seqlens, context_lens, max_q_len,
-                    sampling=None, logprobs=-1):
+                    sampling=None, logprobs=-1, prompt_logprobs=None):
         self.last_sampling = sampling
         assert len(token_ids) == len(positions) == len(slot_mapping) == cu_seqlens[-1]
         self.cache[slot_mapping] = token_ids
@@ -109,9 +109,16 @@ class FakeRunner:
                                           np.arange(context_lens[i] - qlen, context_lens[i]))
             out.append(next_token(self._context(block_tables[i], int(context_lens[i]))))
         self.prefill_tokens.append(int(cu_seqlens[-1]))
+        res = out
         if logprobs >= 0:
-            return out, [(-t / 1000.0, [(t + j, -(t + j) / 1000.0) for j in range(logprobs)]) for t in out]
-        return out
+            res = out, [(-t / 1000.0, [(t + j, -(t + j) / 1000.0) for j in range(logprobs)]) for t in out]
+        if prompt_logprobs is not None:       # fake scores: -(row's own token * 1000 + target) / 1e6
+            k, rows, targets = prompt_logprobs
+            assert len(rows) == len(targets) and (np.diff(rows) > 0).all() and rows[-1] < len(token_ids)
+            self.scored_rows = getattr(self, "scored_rows", 0) + len(rows)
+            score = lambda r, t: -(int(token_ids[r]) * 1000 + int(t)) / 1e6   # noqa: E731
+            return res, [(score(r, t), [(int(t) + j, score(r, t) - j) for j in range(k)]) for r, t in zip(rows, targets)]
+        return res
 
 
 def run(engine):
@@ -354,3 +361,33 @@ def test_logprobs_follow_each_request_own_width():
     for lp, t in zip(seen["b"], toks["b"]):
         assert lp == [(-t / 1000.0, [])]
     assert len(seen["a"]) == 4 and toks["a"] == reference([1, 2, 3], 4)
+
+
+def test_prompt_logprobs_cover_every_prompt_token_once_across_chunks():
+    """echo + logprobs: every prompt token but the first is scored exactly once, by the row before
+    it, however the prompt is cut into prefill chunks; the scores arrive with the first token."""
+    eng, runner = make_engine(num_blocks=64, max_num_seqs=4, max_model_len=256, max_tokens=7)   # 7-token chunks
+    rng = np.random.default_rng(5)
+    ps = [rng.integers(0, V, size=n).tolist() for n in (1, 7, 8, 23)]
+    for i, p in enumerate(ps):
+        eng.add_request(f"r{i}", p, SamplingParams(max_tokens=3, temperature=0.0, logprobs=2 if i % 2 else None,
+                                                   prompt_logprobs=2 if i != 2 else None))
+    first = {}
+    while eng.has_unfinished():
+        for o in eng.step():
+            if o.request_id not in first:
+                first[o.request_id] = o
+            else:
+                assert o.prompt_logprobs is None          # only on the first output
+    for i, p in enumerate(ps):
+        o = first[f"r{i}"]
+        if i == 2:
+            assert o.prompt_logprobs is None
+            continue
+        plp = o.prompt_logprobs
+        assert len(plp) == len(p) and plp[0] is None
+        for j in range(1, len(p)):
+            lp, top = plp[j]
+            assert lp == -(p[j - 1] * 1000 + p[j]) / 1e6       # scored by the row of token j-1 against token j
+            assert [t for t, _ in top] == [p[j], p[j] + 1]
+    assert runner.scored_rows == sum(len(p) - 1 for i, p in enumerate(ps) if i != 2)

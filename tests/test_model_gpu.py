@@ -411,6 +411,50 @@ def test_logprobs_through_the_engine_match_the_oracle():
             assert all(top[j][1] >= top[j + 1][1] for j in range(k - 1)) and lp <= 0
 
 
+@pytest.mark.parametrize("chunk", [8192, 16])
+def test_prompt_logprobs_match_the_oracle(chunk):
+    """`prompt_logprobs=k` (echo + logprobs on the API): the score of every prompt token given the
+    tokens before it against the log-softmax of the oracle's logits at ALL prompt rows, with the
+    prompt prefilled in one piece and in 16-token chunks (a token's score then comes from the
+    last row of the chunk before)."""
+    from mi355_decode.sampling_params import SamplingParams
+    name, k = "llama_d128", 3
+    eng, cfg, w = build(name, "bfloat16", max_num_batched_tokens=chunk)
+    prompts = make_prompts(name, len(LENGTHS), LENGTHS)
+    model = M.RefModel(M.RefConfig(**cfg), w, "bfloat16", num_blocks=len(prompts) * 8)
+    got = {}
+    for i, p in enumerate(prompts):
+        eng.add_request(str(i), [int(t) for t in p], SamplingParams(max_tokens=2, temperature=0.0, ignore_eos=True,
+                                                                   prompt_logprobs=k))
+    while eng.has_unfinished():
+        for o in eng.step():
+            if o.prompt_logprobs is not None:
+                assert o.request_id not in got
+                got[o.request_id] = o.prompt_logprobs
+    worst = 0.0
+    for i, p in enumerate(prompts):
+        n = len(p)
+        bt = np.arange(8, dtype=np.int32)[None] + 8 * i
+        pos = np.arange(n, dtype=np.int64)
+        logits = model.forward(np.asarray(p, dtype=np.int64), pos, (bt[0, pos // 16] * 16 + pos % 16).astype(np.int64), bt,
+                               np.asarray([n], dtype=np.int32), cu_seqlens=np.asarray([0, n], dtype=np.int32),
+                               logits_rows=np.arange(n - 1))
+        logits = R.round_to(logits, "bfloat16")
+        scale = np.abs(logits).max()
+        want, lse = R.token_logprobs(logits, np.asarray(p[1:]))
+        plp = got[str(i)]
+        assert len(plp) == n and plp[0] is None
+        for j in range(1, n):
+            lp, top = plp[j]
+            worst = max(worst, abs(lp - want[j - 1]) / scale)
+            assert abs(lp - want[j - 1]) <= LOGIT_TOL["bfloat16"] * scale * 2, (i, j, lp, want[j - 1])
+            assert len(top) == k and all(top[a][1] >= top[a + 1][1] for a in range(k - 1)) and top[0][1] >= lp - 1e-6
+            # the listed alternatives are the oracle's most likely tokens, up to near-ties
+            ref_lp = logits[j - 1] - lse[j - 1]
+            assert ref_lp[top[0][0]] >= ref_lp.max() - LOGIT_TOL["bfloat16"] * scale * 2
+    print(f"prompt logprobs, chunk {chunk}: worst |diff| {worst:.2e} of the logit scale")
+
+
 def test_failed_graph_capture_falls_back_to_eager_launches(monkeypatch):
     """If the decode step cannot be captured (e.g. a collective the runtime refuses to capture), the
     engine keeps serving with eager launches and the same tokens."""

@@ -118,7 +118,7 @@ def test_errors_are_openai_style_json():
                        ({"prompt": [1], "n": 2}, 400), ({"prompt": [V + 5]}, 400), ({"prompt": []}, 400),
                        ({"prompt": list(range(600))}, 400), ({"prompt": [1], "max_tokens": 0}, 400),
                        ({"prompt": [1], "temperature": -1}, 400), ({"prompt": [1], "top_p": 0}, 400),
-                       ({"prompt": [1], "logprobs": 50}, 400), ({"prompt": [1], "logprobs": 2, "echo": True}, 400)]:
+                       ({"prompt": [1], "logprobs": 50}, 400)]:
         r = c.post("/v1/completions", json=body)
         assert r.status_code == code, (body, r.text)
         err = r.json()["error"]
@@ -172,6 +172,32 @@ def test_prompt_normalisation_and_detokenizer():
     ids = tok.encode("héllo")                               # multi-byte char split over two tokens
     out = "".join(d.push([i]) for i in ids)
     assert out == "héllo"
+
+
+def test_echo_with_logprobs_scores_the_prompt():
+    """`echo` + `logprobs` (log-likelihood scoring as evaluation harnesses do it): the logprobs object
+    starts with one entry per prompt token -- null for the first, then the token's log-probability given
+    the tokens before it, its own entry always present in top_logprobs -- followed by the generated ones."""
+    th, c, _, tok = make()
+    th.ready.wait(10)
+    prompt = [65, 66, 67, 68]
+    r = c.post("/v1/completions", json={"prompt": prompt, "max_tokens": 1, "temperature": 0, "logprobs": 1, "echo": True})
+    assert r.status_code == 200, r.text
+    ch = r.json()["choices"][0]
+    lp = ch["logprobs"]
+    n = len(prompt) + 1
+    assert len(lp["tokens"]) == len(lp["token_logprobs"]) == len(lp["top_logprobs"]) == len(lp["text_offset"]) == n
+    assert lp["token_logprobs"][0] is None and lp["top_logprobs"][0] is None
+    assert all(v is not None and v <= 0 for v in lp["token_logprobs"][1:])
+    for tok, top, v in zip(lp["tokens"][1:len(prompt)], lp["top_logprobs"][1:len(prompt)], lp["token_logprobs"][1:]):
+        assert top[tok] == v and 1 <= len(top) <= 2
+    assert "".join(lp["tokens"]) == ch["text"] and lp["text_offset"][0] == 0
+    assert lp["text_offset"] == [sum(len(t) for t in lp["tokens"][:j]) for j in range(n)]
+    # logprobs: 0 keeps the token scores and drops the alternatives
+    r0 = c.post("/v1/completions", json={"prompt": prompt, "max_tokens": 1, "temperature": 0, "logprobs": 0, "echo": True})
+    lp0 = r0.json()["choices"][0]["logprobs"]
+    assert lp0["top_logprobs"] == [None] * n and lp0["token_logprobs"][1:] == lp["token_logprobs"][1:]
+    th.shutdown()
 
 
 def test_logprobs_object_of_a_completion():

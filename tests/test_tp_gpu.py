@@ -29,6 +29,8 @@ def _free_port():
 
 
 def _worker(rank, world, port, name, dtype, shard_mlp, q):
+    import faulthandler
+    faulthandler.dump_traceback_later(80, exit=True)      # a rank stuck in a collective says where, then leaves
     try:
         for p in (ROOT, os.path.join(ROOT, "vllm-backend-public_amd"), os.path.join(ROOT, "tests")):
             if p not in sys.path:
@@ -61,19 +63,22 @@ def _worker(rank, world, port, name, dtype, shard_mlp, q):
         for i, p in enumerate(make_prompts(name, 3, [7, 19, 30])):
             eng.add_request(f"s{i}", [int(t) for t in p], SamplingParams(max_tokens=6, temperature=0.8, top_k=20,
                                                                        top_p=0.9, seed=5 + i, logprobs=2,
-                                                                       ignore_eos=True))
-            sampled[f"s{i}"] = ([], [])
+                                                                       prompt_logprobs=1, ignore_eos=True))
+            sampled[f"s{i}"] = ([], [], [len(p)])
         while eng.has_unfinished():
             for o in eng.step():
                 sampled[o.request_id][0].extend(o.new_token_ids)
                 sampled[o.request_id][1].extend(o.logprobs or [])
-        for ids, lps in sampled.values():
-            assert len(ids) == 6 and len(lps) == 6
+                if o.prompt_logprobs is not None:
+                    sampled[o.request_id][2].append([None if e is None else [e[0], e[1]] for e in o.prompt_logprobs])
+        for ids, lps, (plen, plp) in sampled.values():
+            assert len(ids) == 6 and len(lps) == 6 and len(plp) == plen and plp[0] is None
+            assert all(e[0] <= 0.0 and len(e[1]) == 1 for e in plp[1:])
             for tok, (lp, top) in zip(ids, lps):
                 assert lp <= 0.0 and len(top) == 2 and top[0][1] >= top[1][1] and top[0][1] >= lp - 1e-6
                 assert 0 <= tok < cfg["vocab_size"] and all(0 <= t < cfg["vocab_size"] for t, _ in top)
-        q.put((rank, "ok", [toks.tolist(), {k: [v[0], [[lp, top] for lp, top in v[1]]] for k, v in sampled.items()}]))
-        dist.barrier()
+        dist.barrier()                                    # both ranks got here: nobody is left inside a collective
+        q.put((rank, "ok", [toks.tolist(), {k: [v[0], [[lp, top] for lp, top in v[1]], v[2]] for k, v in sampled.items()}]))
     except Exception:  # noqa: BLE001
         import traceback
         q.put((rank, traceback.format_exc(), None))
@@ -96,15 +101,22 @@ def test_two_ranks_generate_like_the_unsharded_oracle(name, dtype, shard_mlp):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, name, dtype, shard_mlp, q)) for r in range(2)]
     for p in procs:
         p.start()
+    import queue
+    res = []
     try:
-        res = sorted(q.get(timeout=240) for _ in procs)
+        for _ in procs:
+            res.append(q.get(timeout=100 if not res or res[-1][1] == "ok" else 5))
+    except queue.Empty:
+        pass                                             # a rank that failed leaves its peer waiting in a collective
     finally:
         for p in procs:
-            p.join(60)
+            p.join(5 if len(res) < len(procs) else 60)
             if p.is_alive():
                 p.kill()
     for rank, msg, _ in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+    assert len(res) == len(procs), "a rank produced no result within the time limit"
+    res.sort()
     t0, t1 = np.array(res[0][2][0]), np.array(res[1][2][0])
     assert np.array_equal(t0, t1), "the two ranks sampled different tokens"
     assert res[0][2][1] == res[1][2][1], "the two ranks drew different random samples or log-probabilities"

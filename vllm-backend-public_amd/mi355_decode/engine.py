@@ -71,6 +71,9 @@ class Sequence:
     num_preemptions: int = 0
     seed: int = 0                    # sampling seed (request's, or drawn by the engine)
     inflight: int = 0                # decode steps launched for this sequence and not yet harvested
+    # requests with params.prompt_logprobs: entry j scores prompt token j (None for j = 0), filled
+    # chunk by chunk as the prompt is prefilled
+    prompt_logprobs: Optional[list] = None
 
     @property
     def all_ids(self) -> List[int]:
@@ -99,6 +102,9 @@ class RequestOutput:
     # one entry per new token when the request asked for logprobs: (logprob of the token,
     # [(token id, logprob)] of the most likely tokens, most likely first)
     logprobs: Optional[list] = None
+    # on the output that carries the first generated token of a request with prompt_logprobs: one entry
+    # per prompt token, None for the first, then (logprob, [(token id, logprob)] most likely first)
+    prompt_logprobs: Optional[list] = None
 
 
 class Scheduler:
@@ -318,10 +324,31 @@ class LLMEngine:
             bt[i, : len(seq.blocks)] = seq.blocks
         k = self._logprobs_k([c[0] for c in chunks])
         kw = {"logprobs": k} if k >= 0 else {}
+        # prompt scoring: row r of the packed batch predicts the prompt token after it
+        rows, targets, owners = [], [], []
+        for i, (seq, start, n) in enumerate(chunks):
+            pk = seq.params.prompt_logprobs
+            if pk is None:
+                continue
+            if seq.prompt_logprobs is None:
+                seq.prompt_logprobs = [None]
+            first = max(start, len(seq.prompt_logprobs) - 1)
+            last = min(start + n, len(seq.prompt_ids) - 1)
+            for p_ in range(first, last):
+                rows.append(cu[i] + p_ - start)
+                targets.append(seq.prompt_ids[p_ + 1])
+                owners.append(seq)
+        if rows:
+            kw["prompt_logprobs"] = (max(c[0].params.prompt_logprobs or 0 for c in chunks),
+                                     np.asarray(rows, dtype=np.int64), np.asarray(targets, dtype=np.int64))
         nxt = self.runner.run_prefill(np.concatenate(toks), np.concatenate(pos), np.concatenate(slots), bt,
                                       np.asarray(cu, dtype=np.int32), np.asarray(ctx, dtype=np.int32),
                                       max(n for _, _, n in chunks),
                                       sampling=self._sampling_arrays([c[0] for c in chunks]), **kw)
+        if rows:                                     # (the usual result, one (logprob, top) per scored row)
+            nxt, plps = nxt
+            for seq, (lp, top) in zip(owners, plps):
+                seq.prompt_logprobs.append((lp, top[: seq.params.prompt_logprobs]))
         nxt, lps = nxt if k >= 0 else (nxt, None)
         now = time.perf_counter()
         outs = []
@@ -331,7 +358,10 @@ class LLMEngine:
             self.stats["prefill_tokens"] += n
             if seq.num_computed >= seq.total_len:        # prompt complete: this step sampled a token
                 self._append_token(seq, int(nxt[i]), now)
-                outs.append(self._output(seq, [seq.output_ids[-1]], lps[i] if lps else None))
+                out = self._output(seq, [seq.output_ids[-1]], lps[i] if lps else None)
+                if seq.prompt_logprobs is not None and len(seq.output_ids) == 1:
+                    out.prompt_logprobs = seq.prompt_logprobs
+                outs.append(out)
         return outs
 
     # ------------------------------------------------------------------ #

@@ -126,8 +126,8 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
                 raise ValueError("n > 1 / best_of > 1 are not supported")
             want_lp = body.get("logprobs")
             want_lp = None if want_lp is None or want_lp is False else int(want_lp)
-            if want_lp is not None and body.get("echo"):
-                raise ValueError("logprobs together with echo (prompt log-probabilities) is not supported")
+            # echo + logprobs: the prompt is scored too (how evaluation harnesses compute log-likelihoods)
+            prompt_lp = want_lp if want_lp is not None and body.get("echo") else None
             stop = body.get("stop") or []
             params = SamplingParams(
                 max_tokens=int(body.get("max_tokens", 16) if body.get("max_tokens") is not None else 16),
@@ -137,7 +137,8 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
                 top_k=int(body.get("top_k", -1) if body.get("top_k") is not None else -1),
                 seed=body.get("seed"), stop=[stop] if isinstance(stop, str) else list(stop),
                 stop_token_ids=list(body.get("stop_token_ids") or []),
-                ignore_eos=bool(body.get("ignore_eos", False)), logprobs=want_lp)
+                ignore_eos=bool(body.get("ignore_eos", False)), logprobs=want_lp,
+                prompt_logprobs=prompt_lp)
             for p in prompts:
                 if len(p) + 1 > max_model_len:
                     raise ValueError(f"This model's maximum context length is {max_model_len} tokens; the prompt has "
@@ -171,6 +172,20 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
             if lp_objs[i] is None or not o.logprobs:
                 return None
             step = {"tokens": [], "token_logprobs": [], "top_logprobs": [], "text_offset": []}
+            if getattr(o, "prompt_logprobs", None):           # first output of an echo + logprobs request
+                at = 0
+                for tok, ent in zip(prompts[i], o.prompt_logprobs):
+                    piece = tokenizer.decode([tok])
+                    step["tokens"].append(piece)
+                    step["token_logprobs"].append(None if ent is None else ent[0])
+                    if ent is None or not want_lp:
+                        step["top_logprobs"].append(None)
+                    else:                                     # the prompt token itself is always listed
+                        top = {tokenizer.decode([t]): v for t, v in ent[1]}
+                        top.setdefault(piece, ent[0])
+                        step["top_logprobs"].append(top)
+                    step["text_offset"].append(at)
+                    at += len(piece)
             for tok, (lp, top) in zip(o.new_token_ids, o.logprobs):
                 step["tokens"].append(tokenizer.decode([tok]))
                 step["token_logprobs"].append(lp)

@@ -15,6 +15,8 @@ runs eagerly.
 from __future__ import annotations
 
 import math
+
+import numpy as np
 from typing import Optional
 
 import torch
@@ -90,6 +92,7 @@ class ModelRunner:
         self.max_model_len = int(max_model_len)
         self.max_blocks = (self.max_model_len + BLOCK_SIZE - 1) // BLOCK_SIZE
         self.use_graphs = use_graphs
+        self._device_collectives = None               # decided at the first collective (see _collective)
         self.decode_splits = decode_splits
         self.weight_fp8 = bool(weight_fp8)
 
@@ -341,7 +344,7 @@ class ModelRunner:
             self.in32.copy_(saved32)
         if self.tp_size > 1 and self.tp_group is not None:
             flags = torch.tensor([int(mode[k]) for k in self.KINDS], dtype=torch.int32, device=self.device)
-            torch.distributed.broadcast(flags, src=0, group=self.tp_group)
+            self._collective(lambda c: torch.distributed.broadcast(c, src=0, group=self.tp_group), flags)
             mode = {k: bool(v) for k, v in zip(self.KINDS, flags.tolist())}
         self._modes[bucket] = mode
         return mode
@@ -434,19 +437,43 @@ class ModelRunner:
 
     def _allreduce_max(self, t: torch.Tensor) -> None:
         if self.tp_size > 1:
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.tp_group)
+            self._collective(lambda c: torch.distributed.all_reduce(c, op=torch.distributed.ReduceOp.MAX,
+                                                                    group=self.tp_group), t)
+
+    def _collective(self, fn, t: torch.Tensor) -> None:
+        """Runs the in-place collective fn on t.  RCCL works on the device tensor (and is captured
+        into the decode graph).  Any other backend -- the gloo rehearsal of several ranks on one GPU,
+        eager only -- gets an explicit host copy: gloo's own device-tensor path was seen to stall
+        with both ranks inside the same collective."""
+        if self._device_collectives is None:
+            self._device_collectives = torch.distributed.get_backend(self.tp_group) == "nccl"
+        if self._device_collectives:
+            fn(t)
+        else:
+            c = t.cpu()
+            fn(c)
+            t.copy_(c)
 
     def full_logits(self, logits: torch.Tensor) -> torch.Tensor:
         """[rows, vocab_size] logits from this rank's slice (sampling and log-probabilities need the
         whole row; greedy steps never gather)."""
         if not self.vocab_sharded:
             return logits
-        parts = [torch.empty_like(logits, memory_format=torch.contiguous_format) for _ in range(self.tp_size)]
-        self._allgather(parts, logits.contiguous())
-        return torch.cat(parts, dim=1)
+        return self._gather_columns(logits.contiguous())
 
-    def _allgather(self, parts, t: torch.Tensor) -> None:
-        torch.distributed.all_gather(parts, t, group=self.tp_group)
+    def _gather_columns(self, t: torch.Tensor) -> torch.Tensor:
+        """Concatenation over the ranks of their [rows, Vl] slices, on every rank.  RCCL: one
+        all-gather.  Other backends (the gloo rehearsal of several ranks on one GPU): a sum all-reduce of the slice placed in a zero row
+        of full width -- x + 0 is exact, so the values are the same."""
+        rows = t.shape[0]
+        if torch.distributed.get_backend(self.tp_group) == "nccl":
+            buf = torch.empty(self.tp_size, rows, self.Vl, dtype=t.dtype, device=t.device)
+            torch.distributed.all_gather_into_tensor(buf, t, group=self.tp_group)
+            return buf.permute(1, 0, 2).reshape(rows, self.V)
+        full = torch.zeros(rows, self.V, dtype=t.dtype, device=t.device)
+        full[:, self.vocab_offset:self.vocab_offset + self.Vl] = t
+        self._allreduce(full)
+        return full
 
     def kv_cache_bytes_per_block(self) -> int:
         return 2 * self.L * self.nkv * BLOCK_SIZE * self.d * self.k_cache[0].element_size()
@@ -461,7 +488,7 @@ class ModelRunner:
 
     def _allreduce(self, t: torch.Tensor) -> None:
         if self.tp_size > 1:
-            torch.distributed.all_reduce(t, group=self.tp_group)
+            self._collective(lambda c: torch.distributed.all_reduce(c, group=self.tp_group), t)
 
     def _layers(self, n: int, resid, x, qkv, attn, o, gu, act, dn, attend) -> torch.Tensor:
         """Runs all decoder layers over n packed tokens held in `resid`.  Returns the
@@ -631,34 +658,47 @@ class ModelRunner:
         return self.finish_decode(batch, 0)
 
     def run_prefill(self, token_ids, positions, slot_mapping, block_tables, cu_seqlens, context_lens,
-                    max_q_len: int, sampling: Optional[dict] = None, logprobs: int = -1):
+                    max_q_len: int, sampling: Optional[dict] = None, logprobs: int = -1, prompt_logprobs=None):
         """Host-facing prefill step over numpy inputs; returns next-token ids (list), and with
-        `logprobs` >= 0 also their log-probabilities (as finish_decode)."""
+        `logprobs` >= 0 also their log-probabilities (as finish_decode).  `prompt_logprobs` =
+        (k, rows, targets) additionally scores packed rows `rows` against the tokens `targets` that
+        follow them in their prompts: the result becomes (the usual result, [(logprob of the target,
+        [(token id, logprob)] * k)] per scored row)."""
         dev = self.device
 
         def t(a, dt):
             return torch.from_numpy(a).to(dev, dtype=dt, non_blocking=True)
 
+        score = None
+        if prompt_logprobs is not None:
+            pk, rows, targets = prompt_logprobs
+            score = (int(pk), t(np.asarray(rows), torch.int64), t(np.asarray(targets), torch.int64))
         nxt, logits = self.prefill(t(token_ids, torch.int64), t(positions, torch.int64), t(slot_mapping, torch.int64),
                                    t(block_tables, torch.int32), t(cu_seqlens, torch.int32),
                                    t(context_lens, torch.int32), int(max_q_len),
-                                   want_logits=sampling is not None or logprobs >= 0)
+                                   want_logits=sampling is not None or logprobs >= 0, score=score)
         if sampling is not None:
             self._sample(logits, sampling, nxt)
         if logprobs >= 0:
             lp = self._logprobs(logits, nxt, logprobs).cpu().numpy()
-            return nxt.cpu().tolist(), self._unpack_logprobs(lp, logprobs)
-        return nxt.cpu().tolist()
+            res = nxt.cpu().tolist(), self._unpack_logprobs(lp, logprobs)
+        else:
+            res = nxt.cpu().tolist()
+        if score is not None:
+            return res, self._unpack_logprobs(self.prompt_scores.cpu().numpy(), score[0])
+        return res
 
     # ------------------------------------------------------------------ #
     # prefill: packed variable-length prompts (or prompt chunks), eager
     # ------------------------------------------------------------------ #
     def prefill(self, token_ids: torch.Tensor, positions: torch.Tensor, slot_mapping: torch.Tensor,
                 block_tables: torch.Tensor, cu_seqlens: torch.Tensor, context_lens: torch.Tensor,
-                max_q_len: int, want_logits: bool = True):
+                max_q_len: int, want_logits: bool = True, score=None):
         """token_ids/positions/slot_mapping: int64 [T] on the device; block_tables
         int32 [S, max_blocks]; cu_seqlens int32 [S+1]; context_lens int32 [S].
-        Returns (greedy next token per sequence [S], logits [S, V] or None)."""
+        Returns (greedy next token per sequence [S], logits [S, V] or None).  `score` = (k, rows,
+        targets) leaves in self.prompt_scores the _logprobs rows of packed rows `rows` scored
+        against `targets` (the lm_head runs over those rows too, 1024 at a time)."""
         T = token_ids.numel()
         f = dict(dtype=self.dtype, device=self.device)
         resid = torch.index_select(self.w.embed, 0, token_ids)
@@ -683,6 +723,18 @@ class ModelRunner:
         resid_sel = resid.index_select(0, rows)
         xs = torch.empty_like(last_sel)
         ops.fused_add_rms_norm(last_sel, resid_sel, self.w.final_norm, self.eps, out=xs)
+        if score is not None:
+            k, srows, targets = score
+            parts = []
+            for a in range(0, srows.numel(), 1024):
+                sel = srows[a:a + 1024]
+                hs = torch.empty(sel.numel(), self.H, **f)
+                # the final norm adds into its residual argument: work on copies of the selected rows
+                ops.fused_add_rms_norm(last.index_select(0, sel), resid.index_select(0, sel), self.w.final_norm,
+                                       self.eps, out=hs)
+                lg = self.full_logits(torch.mm(hs, self.w.lm_head.t()))
+                parts.append(self._logprobs(lg, targets[a:a + 1024], k))
+            self.prompt_scores = torch.cat(parts, dim=0)
         logits = torch.mm(xs, self.w.lm_head.t())
         nxt = torch.empty(logits.shape[0], dtype=torch.int64, device=self.device)
         self.greedy(logits, nxt)

@@ -18,6 +18,9 @@ class SamplingParams:
     stop_token_ids: List[int] = field(default_factory=list)
     ignore_eos: bool = False
     logprobs: Optional[int] = None
+    # also score the prompt: log-probability of every prompt token given the ones before it
+    # (and the `prompt_logprobs` most likely alternatives); what `echo` + `logprobs` asks for
+    prompt_logprobs: Optional[int] = None
     n: int = 1
 
     def __post_init__(self):
@@ -34,6 +37,8 @@ class SamplingParams:
         self.stop = list(self.stop or [])
         if self.logprobs is not None and not 0 <= int(self.logprobs) <= 20:
             raise ValueError("logprobs must be between 0 and 20")
+        if self.prompt_logprobs is not None and not 0 <= int(self.prompt_logprobs) <= 20:
+            raise ValueError("prompt_logprobs must be between 0 and 20")
         if self.n != 1:
             raise ValueError("n > 1 is not supported")
 
