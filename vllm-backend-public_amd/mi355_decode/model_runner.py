@@ -172,6 +172,8 @@ class ModelRunner:
         self.tiled = None
         self._modes = {}
         self._plan_cache = {}
+        self._tuned_plans = {}                        # bucket -> {projection: (tiles_per_wg, k_groups)} picked by tune()
+        self._tuned_classes = {}                      # kernel row class (16/32/64/128) -> (mode, plans) already timed
         self.tiled_shapes = {}
         if self.tiled_policy == "off" or self.dtype not in (torch.bfloat16, torch.float16) or (2 * self.F) % 32:
             return
@@ -200,10 +202,10 @@ class ModelRunner:
         self.lm_head_tiled = ops.tile_weights(self.w.lm_head) if "lm_head" in self.tiled_shapes else None
         f32 = dict(dtype=torch.float32, device=self.device)
         size = {k: 0 for k in ("qkv", "o", "down")}
-        for m in ms:
+        for m in ms:                                  # room for the deepest K split the tuner may pick (8 slabs)
             for k in size:
                 if k in self._tiled_plan(m):
-                    size[k] = max(size[k], self._tiled_plan(m)[k][1] * m * self.tiled_shapes[k][0])
+                    size[k] = max(size[k], 8 * min(m, max(self.max_num_seqs, 16)) * self.tiled_shapes[k][0])
         self.part_qkv = torch.empty(max(size["qkv"], 4), **f32)
         self.part_o = torch.empty(max(size["o"], 4), **f32)
         self.part_dn = torch.empty(max(size["down"], 4), **f32)
@@ -229,6 +231,8 @@ class ModelRunner:
 
     def _tiled_plan(self, m: int):
         """{projection: (tiles_per_wg, k_groups)} of the projections that have a tiled kernel for m rows."""
+        if m in self._tuned_plans:
+            return self._tuned_plans[m]
         if m not in self._plan_cache:
             plans = {}
             if m <= ops.LINEAR_TILED_MAX_M:
@@ -269,83 +273,100 @@ class ModelRunner:
         e.synchronize()
         return s.elapsed_time(e) * 1e3 / (2 * reps * self.L)
 
+    @staticmethod
+    def _row_class(m: int) -> int:
+        return 16 if m <= 16 else 32 if m <= 32 else 64 if m <= 64 else 128
+
     def tune(self, bucket: int) -> dict:
-        """Decides, for one batch-size bucket, which projections run on the tiled kernels: times
-        each one both ways (GEMM plus the consumer kernel whose input format it changes) on
-        scratch activations and neutral step inputs.  Under tensor parallelism rank 0's decisions are broadcast: the
-        replicated projections must round the same way on every rank, or the ranks' greedy
-        tokens could part."""
+        """Decides, for one batch-size bucket, how every projection runs: times the tiled kernel in
+        each workgroup shape / K split it is built for and the library GEMM (each with the consumer
+        kernel whose input format it changes) on scratch activations and neutral step inputs, and
+        keeps the fastest.  Buckets that fall in the same row class of the kernels (16/32/64/128)
+        share one timing.  Under tensor parallelism rank 0's decisions are broadcast: the replicated
+        projections must round the same way on every rank, or the ranks' greedy tokens could part."""
         if bucket in self._modes:
             return self._modes[bucket]
-        avail = self._tiled_plan(bucket) if self.tiled is not None else {}
+        avail = dict(self._tiled_plan(bucket)) if self.tiled is not None else {}
         mode = {k: k in avail for k in self.KINDS}
-        if self.tiled_policy == "auto" and avail:
+        cls = self._row_class(bucket)
+        if self.tiled_policy == "auto" and avail and cls in self._tuned_classes:
+            mode, avail = self._tuned_classes[cls]
+        elif self.tiled_policy == "auto" and avail:
             b = bucket
             # neutral step inputs while timing (no KV store, empty contexts); the staged ones come back after
             saved64, saved32 = self.in64.clone(), self.in32.clone()
             self.slots.fill_(-1)
             self.in32.zero_()
             slots, ctx, bt, splits = self.slots[:b], self.ctx[:b], self.block_tables[:b], self._splits_for(b)
+            resid, x, qkv, attn, act, o, gu, dn = (t[:b] for t in (self.resid, self.x, self.qkv, self.attn, self.act,
+                                                                  self.o, self.gu, self.dn))
+            W, T, P, eps = self.w.layers, self.tiled, ops.EPI_PARTIAL, self.eps
+            lt = self._linear_tiled
 
             def attend(i, **kw):
                 ops.paged_attn_decode_fused(kw.pop("qkv", None), self.cos_sin, slots, self.k_cache[i], self.v_cache[i],
                                             bt, ctx, self.nh, self.nkv, self.d, self.scale, num_splits=splits,
                                             workspace=self.attn_ws, out=attn, **kw)
-            resid, x, qkv, attn, act, o, gu, dn = (t[:b] for t in (self.resid, self.x, self.qkv, self.attn, self.act,
-                                                                  self.o, self.gu, self.dn))
-            W, T, P, eps = self.w.layers, self.tiled, ops.EPI_PARTIAL, self.eps
-            lt = self._linear_tiled
-            forms = {}
-            if "qkv" in avail:
-                t_, g_ = avail["qkv"]
-                forms["qkv"] = (lambda i: (lt(x, T[i]["qkv"], self.qw, partial=self.part_qkv, tiles_per_wg=t_,
-                                              k_groups=g_, epilogue=P),
-                                           attend(i, partial=self.part_qkv, num_slabs=g_, bias=W[i].qkv_b)),
-                                lambda i: (torch.mm(x, W[i].qkv_w.t(), out=qkv), attend(i, qkv=qkv)))
-            if "o" in avail:
-                to, go = avail["o"]
-                forms["o"] = (lambda i: (lt(attn, T[i]["o"], self.H, partial=self.part_o, tiles_per_wg=to, k_groups=go,
-                                            epilogue=P),
-                                         ops.fused_add_rms_norm_partial(self.part_o, go, resid, W[i].post_norm, eps, x)),
-                              lambda i: (torch.mm(attn, W[i].o_w.t(), out=o),
-                                         ops.fused_add_rms_norm(o, resid, W[i].post_norm, eps, out=x)))
-            if "gu" in avail:
-                tg = avail["gu"][0]
-                forms["gu"] = (lambda i: lt(x, T[i]["gu"], 2 * self.F, out=act, tiles_per_wg=tg,
-                                            epilogue=ops.EPI_SILU_MUL),
-                               lambda i: (torch.mm(x, W[i].gate_up_w.t(), out=gu), ops.silu_and_mul(gu, out=act)))
-            if "down" in avail:
-                td, gd = avail["down"]
-                forms["down"] = (lambda i: (lt(act, T[i]["down"], self.H, partial=self.part_dn, tiles_per_wg=td,
-                                               k_groups=gd, epilogue=P),
-                                            ops.fused_add_rms_norm_partial(self.part_dn, gd, resid, W[i].input_norm, eps, x)),
-                                 lambda i: (torch.mm(act, W[i].down_w.t(), out=dn),
-                                            ops.fused_add_rms_norm(dn, resid, W[i].input_norm, eps, out=x)))
-            if "lm_head" in avail:
-                th = avail["lm_head"][0]
-                forms["lm_head"] = (lambda i: ops.linear_tiled(x, self.lm_head_tiled, self.Vl, out=self.logits[:b],
-                                                               tiles_per_wg=th),
-                                    lambda i: torch.mm(x, self.w.lm_head.t(), out=self.logits[:b]))
+
+            # projection -> (tiled form for a (tiles_per_wg, k_groups) plan, library form)
+            forms = {
+                "qkv": (lambda t_, g_: lambda i: (lt(x, T[i]["qkv"], self.qw, partial=self.part_qkv, tiles_per_wg=t_,
+                                                     k_groups=g_, epilogue=P),
+                                                  attend(i, partial=self.part_qkv, num_slabs=g_, bias=W[i].qkv_b)),
+                        lambda i: (torch.mm(x, W[i].qkv_w.t(), out=qkv), attend(i, qkv=qkv))),
+                "o": (lambda t_, g_: lambda i: (lt(attn, T[i]["o"], self.H, partial=self.part_o, tiles_per_wg=t_,
+                                                   k_groups=g_, epilogue=P),
+                                                ops.fused_add_rms_norm_partial(self.part_o, g_, resid, W[i].post_norm,
+                                                                               eps, x)),
+                      lambda i: (torch.mm(attn, W[i].o_w.t(), out=o),
+                                 ops.fused_add_rms_norm(o, resid, W[i].post_norm, eps, out=x))),
+                "gu": (lambda t_, g_: lambda i: lt(x, T[i]["gu"], 2 * self.F, out=act, tiles_per_wg=t_,
+                                                   epilogue=ops.EPI_SILU_MUL),
+                       lambda i: (torch.mm(x, W[i].gate_up_w.t(), out=gu), ops.silu_and_mul(gu, out=act))),
+                "down": (lambda t_, g_: lambda i: (lt(act, T[i]["down"], self.H, partial=self.part_dn, tiles_per_wg=t_,
+                                                      k_groups=g_, epilogue=P),
+                                                   ops.fused_add_rms_norm_partial(self.part_dn, g_, resid,
+                                                                                  W[i].input_norm, eps, x)),
+                         lambda i: (torch.mm(act, W[i].down_w.t(), out=dn),
+                                    ops.fused_add_rms_norm(dn, resid, W[i].input_norm, eps, out=x))),
+                "lm_head": (lambda t_, g_: lambda i: ops.linear_tiled(x, self.lm_head_tiled, self.Vl,
+                                                                      out=self.logits[:b], tiles_per_wg=t_),
+                            lambda i: torch.mm(x, self.w.lm_head.t(), out=self.logits[:b])),
+            }
             self.tune_us = getattr(self, "tune_us", {})
             try:
-                for k, (tiled_fn, lib_fn) in forms.items():
+                for k in [k for k in self.KINDS if k in avail]:
+                    tiled_form, lib_fn = forms[k]
+                    n, kk, split = self.tiled_shapes[k]
+                    best, best_us = avail[k], None
+                    for cand in ops.linear_tiled_candidates(n, kk, split, b):
+                        us = self._time_launches(tiled_form(*cand))
+                        if best_us is None or us < 0.98 * best_us:      # the planner's own choice unless clearly beaten
+                            best, best_us = cand, us
                     lib_fn(0)                               # first library call may pick its algorithm
-                    tt, tl = self._time_launches(tiled_fn), self._time_launches(lib_fn)
-                    self.tune_us[(bucket, k)] = (round(tt, 2), round(tl, 2))
-                    mode[k] = tt <= tl
+                    tl = self._time_launches(lib_fn)
+                    self.tune_us[(bucket, k)] = (round(best_us, 2), round(tl, 2))
+                    avail[k] = best
+                    mode[k] = best_us <= tl
             except RuntimeError as exc:                     # timing replays graphs: without them, no choice is made
                 import logging
                 logging.getLogger("mi355_decode").warning(
                     "timing the GEMM forms for batch bucket %d failed (%s); using the tiled kernels", bucket, exc)
                 torch.cuda.synchronize()
+                avail = dict(self._tiled_plan(bucket))
                 mode = {k: k in avail for k in self.KINDS}
             resid.zero_()                                   # the timed norms accumulated into it
             self.in64.copy_(saved64)
             self.in32.copy_(saved32)
         if self.tp_size > 1 and self.tp_group is not None:
-            flags = torch.tensor([int(mode[k]) for k in self.KINDS], dtype=torch.int32, device=self.device)
+            flat = [v for k in self.KINDS for v in (int(mode[k]), *avail.get(k, (0, 0)))]
+            flags = torch.tensor(flat, dtype=torch.int32, device=self.device)
             self._collective(lambda c: torch.distributed.broadcast(c, src=0, group=self.tp_group), flags)
-            mode = {k: bool(v) for k, v in zip(self.KINDS, flags.tolist())}
+            flat = flags.tolist()
+            mode = {k: bool(flat[3 * i]) for i, k in enumerate(self.KINDS)}
+            avail = {k: (flat[3 * i + 1], flat[3 * i + 2]) for i, k in enumerate(self.KINDS) if k in avail}
+        self._tuned_classes[cls] = (mode, avail)
+        self._tuned_plans[bucket] = avail
         self._modes[bucket] = mode
         return mode
 
@@ -482,7 +503,10 @@ class ModelRunner:
         if self.decode_splits:
             return int(self.decode_splits)
         wgs = batch * self.nkv
-        want = max(1, 512 // max(wgs, 1))
+        # a split repeats the query prologue and adds a merge pass: it pays only while the unsplit
+        # launch would leave CUs idle (measured at 256 workgroups, contexts 512-1024: 1 split 27.8 us,
+        # 2 splits 37.0, 4 splits 42.0)
+        want = max(1, 256 // max(wgs, 1))
         by_len = max(1, self.max_model_len // 256)      # keep >= 2 wave-steps per workgroup
         return max(1, min(want, by_len, self._max_splits))
 

@@ -418,6 +418,27 @@ def plan_linear_tiled(N: int, K: int, split_k: bool, M: int = 32):
     return None
 
 
+def linear_tiled_candidates(N: int, K: int, split_k: bool, M: int = 32):
+    """Every (tiles_per_wg, k_groups) worth timing for linear_tiled on an [N, K] weight and M rows:
+    both workgroup shapes that every kernel form (fp8, fused epilogues) is built for, K split into
+    1, 2, 4 or 8 groups when the caller can take partial sums, kept if the launch has between 64
+    and 1024 workgroups.  plan_linear_tiled's choice comes first."""
+    first = plan_linear_tiled(N, K, split_k, M)
+    if first is None:
+        return []
+    out = [first]
+    tiles_total = (N + 15) // 16
+    for tiles in ((8, 104) if M <= 64 else (8,)):
+        ksl = tiled_slice_width(M, tiles)
+        if K % ksl:
+            continue
+        wgs = -(-tiles_total // (tiles % 100))
+        for g in ((1, 2, 4, 8) if split_k else (1,)):
+            if g <= K // ksl and 64 <= wgs * g <= 1024 and (tiles, g) not in out:
+                out.append((tiles, g))
+    return out
+
+
 def tile_weights(weight: torch.Tensor, interleave_halves: bool = False) -> torch.Tensor:
     """Row-major [N, K] -> fragment-tiled flat tensor for linear_tiled (done once at load)."""
     _dt16(weight, "weight")
