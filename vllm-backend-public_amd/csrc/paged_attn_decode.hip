@@ -561,7 +561,6 @@ static int32_t decode_entry(const char* name, void* out, const void* q, int64_t 
     if (ra.num_slabs == 1) MI355_DEC(TT, DD, 2, 1);         \
     if (ra.num_slabs == 2) MI355_DEC(TT, DD, 2, 2);         \
     if (ra.num_slabs == 4) MI355_DEC(TT, DD, 2, 4);         \
-    if (ra.num_slabs == 8) MI355_DEC(TT, DD, 2, 8);         \
     MI355_DEC(TT, DD, 2, 0);                                \
   } while (0)
   if (dtype == MI355_BF16) {

@@ -152,6 +152,9 @@ class ModelRunner:
 
     # ------------------------------------------------------------------ #
     KINDS = ("qkv", "o", "gu", "down", "lm_head")
+    # the fused attention kernel sums up to 4 slabs of the qkv projection with straight-line loads
+    # (more would not fit its registers); deeper K splits of qkv would take its slow generic prologue
+    QKV_MAX_SLABS = 4
 
     def _init_tiled(self, want: Optional[bool]) -> None:
         """Fragment-tiled copies of the weights for decode batches of up to 128 rows.
@@ -237,7 +240,10 @@ class ModelRunner:
             plans = {}
             if m <= ops.LINEAR_TILED_MAX_M:
                 plans = {k: ops.plan_linear_tiled(n, kk, split, m) for k, (n, kk, split) in self.tiled_shapes.items()}
-            self._plan_cache[m] = {k: p for k, p in plans.items() if p is not None}
+            plans = {k: p for k, p in plans.items() if p is not None}
+            if "qkv" in plans:                          # see QKV_MAX_SLABS
+                plans["qkv"] = (plans["qkv"][0], min(plans["qkv"][1], self.QKV_MAX_SLABS))
+            self._plan_cache[m] = plans
         return self._plan_cache[m]
 
     def _mode(self, b: int) -> dict:
@@ -340,9 +346,13 @@ class ModelRunner:
                     n, kk, split = self.tiled_shapes[k]
                     best, best_us = avail[k], None
                     for cand in ops.linear_tiled_candidates(n, kk, split, b):
+                        if k == "qkv" and cand[1] > self.QKV_MAX_SLABS:
+                            continue
                         us = self._time_launches(tiled_form(*cand))
                         if best_us is None or us < 0.98 * best_us:      # the planner's own choice unless clearly beaten
                             best, best_us = cand, us
+                    if best_us is None:
+                        best_us = self._time_launches(tiled_form(*best))
                     lib_fn(0)                               # first library call may pick its algorithm
                     tl = self._time_launches(lib_fn)
                     self.tune_us[(bucket, k)] = (round(best_us, 2), round(tl, 2))
