@@ -46,13 +46,20 @@ class ResultsStub(http.server.BaseHTTPRequestHandler):
         pass
 
 
-def test_harness_plumbing_pass(tmp_path):
+@pytest.mark.parametrize("case,tp", [("cfg2_llama3_8b_tp1", 1), ("cfg3_llama3_8b_tp4", 2)], ids=["tp1", "tp2_one_gpu"])
+def test_harness_plumbing_pass(tmp_path, case, tp):
+    """tp2_one_gpu: the tensor-parallel server as the harness launches it (--tensor-parallel-size from
+    the TP config's args, cut to 2): rank 0 serves HTTP and starts the worker rank itself, requests
+    reach the worker over the control channel, both step in lock-step exchanging partial sums -- the
+    two ranks share this box's one GPU and talk over gloo, which RCCL would not allow."""
     import torch
     assert torch.cuda.is_available()
     from mi355_decode.harness import BenchClient, evaluation_payload, result_pk
 
     launch = json.load(open(os.path.join(GOLDEN, "harness_launch.json")))
-    args = list(launch["cases"]["cfg2_llama3_8b_tp1"]["deployment"]["args"])
+    args = list(launch["cases"][case]["deployment"]["args"])
+    args[args.index("--tensor-parallel-size") + 1] = str(tp)
+    args[args.index("--max-num-seqs") + 1] = "8"
     model_dir = tmp_path / "tiny-llama"
     model_dir.mkdir()
     arch, cfg, _ = TINY["llama_d128"]
@@ -63,11 +70,13 @@ def test_harness_plumbing_pass(tmp_path):
     args[args.index("--host") + 1] = "127.0.0.1"
     args[args.index("--max-model-len") + 1] = "256"
     env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + ROOT)
-    for e in launch["cases"]["cfg2_llama3_8b_tp1"]["deployment"]["env"]:     # the harness's env, CUDA_VISIBLE_DEVICES="" included
+    for e in launch["cases"][case]["deployment"]["env"]:     # the harness's env, CUDA_VISIBLE_DEVICES="" included
         env[e["name"]] = e["value"]
+    if tp > 1:
+        env["MI355_DIST_BACKEND"] = "gloo"
     log = open(tmp_path / "server.log", "w")
     proc = subprocess.Popen([sys.executable, "-m", "mi355_decode.entrypoints.openai.api_server"] + args,
-                            env=env, stdout=log, stderr=subprocess.STDOUT)
+                            env=env, stdout=log, stderr=subprocess.STDOUT, start_new_session=True)
     stub = http.server.ThreadingHTTPServer(("127.0.0.1", 0), ResultsStub)
     threading.Thread(target=stub.serve_forever, daemon=True).start()
     try:
@@ -86,7 +95,7 @@ def test_harness_plumbing_pass(tmp_path):
             assert time.time() - t0 < 240, "server did not become healthy"
             time.sleep(0.2)
         served = client.wait_ready(tries=30, delay=0.5)
-        assert served == "llama-3-8b"                 # --served-model-name from the harness config
+        assert served == args[args.index("--served-model-name") + 1]
 
         # the evaluation job: 4 token-id prompts, greedy, streaming
         outs = []
@@ -108,11 +117,20 @@ def test_harness_plumbing_pass(tmp_path):
         assert codes == [200, 200]
         assert ("/raw_input", result_pk(payload)) in ResultsStub.stored
         assert ResultsStub.stored[("/standardized_output", result_pk(payload))]["data"]["requests"] == 4
+        log.flush()
+        text = open(tmp_path / "server.log").read()
+        for r in range(tp):                           # every rank really came up, with the sharding its size implies
+            assert f"tensor-parallel rank {r} of {tp}" in text, text[-2000:]
+        assert ("MLP sharded, lm_head sharded" in text) == (tp > 1)
     finally:
         proc.terminate()
         try:
-            proc.wait(20)
+            proc.wait(30)
         except subprocess.TimeoutExpired:
-            proc.kill()
+            pass
+        try:                                          # whatever is left of the server's own process group (TP workers)
+            os.killpg(proc.pid, 9)
+        except ProcessLookupError:
+            pass
         stub.shutdown()
         log.close()

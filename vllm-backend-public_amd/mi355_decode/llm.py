@@ -32,10 +32,12 @@ def init_distributed(tp_size: int):
         if world != tp_size:
             raise RuntimeError(f"--tensor-parallel-size {tp_size} needs {tp_size} processes "
                                f"(WORLD_SIZE={world}); launch with torch.distributed.run")
+        backend = os.environ.get("MI355_DIST_BACKEND", "nccl")
+        if backend != "nccl":                          # rehearsal: the ranks share whatever cards there are
+            local %= max(torch.cuda.device_count(), 1)
         device = torch.device("cuda", local)
         torch.cuda.set_device(device)
         if not torch.distributed.is_initialized():
-            backend = os.environ.get("MI355_DIST_BACKEND", "nccl")
             if backend == "nccl":
                 torch.distributed.init_process_group("nccl", device_id=device)
             else:
@@ -106,9 +108,14 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
     tiled_bytes += weights.lm_head.numel() * weights.lm_head.element_size()
     num_blocks = plan_num_blocks(args, cfg, tp, len(weights.layers), max_model_len,
                                  torch.empty(0, dtype=dtype).element_size(), device, extra_reserve=tiled_bytes)
+    # only RCCL collectives can be captured into the decode graph
+    graphs = not args.enforce_eager and (tp == 1 or torch.distributed.get_backend(group) == "nccl")
     runner = ModelRunner(cfg, weights, dtype, device, num_blocks, args.max_num_seqs, max_model_len,
-                         tp_rank=rank, tp_size=tp, tp_group=group, use_graphs=not args.enforce_eager,
+                         tp_rank=rank, tp_size=tp, tp_group=group, use_graphs=graphs,
                          decode_splits=decode_splits, weight_fp8=(args.quantization or "").lower() == "fp8")
+    log.info("tensor-parallel rank %d of %d on %s: %d layers, MLP %s, lm_head %s, %d KV pages, HIP graphs %s",
+             rank, tp, device, len(weights.layers), "sharded" if shard_mlp else "whole",
+             "sharded" if shard_vocab else "whole", num_blocks, "on" if graphs else "off")
     eos = cfg.eos_token_id
     eos = [] if eos is None else (list(eos) if isinstance(eos, (list, tuple)) else [eos])
     return LLMEngine(runner, args.max_num_seqs, max(args.max_num_batched_tokens, 1), max_model_len, eos,
