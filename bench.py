@@ -348,7 +348,9 @@ def main():
         for k in range(seg):
             engine.step()
         barrier()
-        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=engine.device)
+        # RCCL reduces device tensors; any other backend (a rehearsal over gloo) gets a host tensor
+        on_dev = world > 1 and dist.get_backend() == "nccl"
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=engine.device if on_dev else "cpu")
         if world > 1:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         total_t += float(dt.item())
@@ -383,7 +385,7 @@ def main():
                                    + ("sharded over the vocabulary, greedy keys max-reduced)" if vocab_tp > 1 else "replicated)")
                                    if mlp_tp > 1 else
                                    f"tp{tp} (attention heads sharded, MLP+lm_head replicated)") if tp > 1 else "tp1",
-                   "mean_context": round(mean_ctx, 1), "hip_graphs": not a.eager},
+                   "mean_context": round(mean_ctx, 1), "hip_graphs": bool(engine.runner.use_graphs)},
         "ttft_ms_p50": round(ttft_ms, 2),
         "step_roofline": {"bound": "hbm", "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(step_gbs / HBM_PEAK_GBS, 4), "bytes_per_step": int(step_bytes),
@@ -392,15 +394,20 @@ def main():
     if a.layers:
         result["config"]["INVALID_reduced_layers"] = a.layers
 
+    kern = None
     if rank == 0 and not a.no_kernel_timing:
-        kern = time_kernels(engine, batch, int(mean_ctx))
+        try:
+            kern = time_kernels(engine, batch, int(mean_ctx))
+        except Exception as exc:                          # never lose the step measurement to the per-kernel table
+            result["kernels"] = {"error": repr(exc)}
+    if kern is not None:
         result["kernels"] = kern
         dom = kern["gemm_gate_up"]
         tiled = engine.runner._mode(batch)["gu"]
-        traffic, src = pmc_traffic(tiled)
+        traffic, src = pmc_traffic(tiled) if tp == 1 else (None, None)   # the PMC passes were of the 1-GPU workload
         result["roofline"] = {"bound": "hbm",
                               "kernel": ("gate/up projection GEMM%s (M=%d, N=%d, K=%d): %s" % (
-                                  " + SwiGLU epilogue" if tiled else "", batch, 2 * cfg.intermediate_size,
+                                  " + SwiGLU epilogue" if tiled else "", batch, 2 * engine.runner.F,
                                   cfg.hidden_size, "linear_tiled_kernel" if tiled else "hipBLASLt")),
                               "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
                               "traffic": traffic, "traffic_source": (src or "none") +
