@@ -702,7 +702,8 @@ def test_linear_tiled_norm_prologue(ops, dtype, M, H, N2, tiles, epi):
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 @pytest.mark.parametrize("M,N,K,tiles,groups", [(64, 4096, 4096, 104, 4), (33, 1000, 1024, 8, 1), (64, 6144, 4096, 8, 1),
                                                 (128, 4096, 14336, 8, 7), (100, 1536, 4096, 8, 8), (65, 320, 512, 8, 1),
-                                                (128, 28672, 4096, 8, 1), (48, 4096, 1024, 104, 2)])
+                                                (128, 28672, 4096, 8, 1), (48, 4096, 1024, 104, 2),
+                                                (64, 4096, 4096, 108, 4), (40, 1000, 1024, 108, 1), (64, 4736, 3584, 108, 1)])
 def test_linear_tiled_up_to_128_rows(ops, dtype, M, N, K, tiles, groups):
     """33..128 rows (more m-tiles per wave, narrower x slices): store, partial slabs and the
     in-launch reduction against the fp64 product; the reduction bit-identical to the slab sum."""
@@ -887,7 +888,8 @@ def test_tile_weights_fp8(ops, dtype, N, K, inter):
 @pytest.mark.parametrize("M,N,K,tiles,groups,bias", [(32, 4096, 4096, 104, 4, False), (32, 28672, 4096, 8, 1, False),
                                                      (7, 1000, 1024, 104, 1, True), (64, 3584, 18944, 104, 4, False),
                                                      (128, 4608, 3584, 8, 7, True), (1, 64, 512, 104, 1, False),
-                                                     (48, 6144, 4096, 8, 1, True)])
+                                                     (48, 6144, 4096, 8, 1, True), (64, 3584, 18944, 108, 8, False),
+                                                     (48, 6144, 4096, 108, 1, True)])
 def test_linear_tiled_w8(ops, dtype, M, N, K, tiles, groups, bias):
     rng = rng_for("w8", dtype, M, N, K)
     x, w = grid(rng, (M, K), dtype), grid(rng, (N, K), dtype, 0.05)

@@ -16,7 +16,7 @@
 // through LDS one KSL-wide slice (a "phase") at a time, double buffered: the
 // global loads of slice p+1 are issued at the start of phase p and written to the
 // other LDS buffer at its end, one workgroup barrier per phase.  Weight loads run
-// through a ring of 4 register groups of 4 k-steps (4 KB each), three groups
+// through a ring of 2 register groups of 4 k-steps (4 KB each), one group
 // ahead of the MFMAs; scheduling barriers pin loads where they are written (the
 // compiler otherwise sinks every load down to its use and the wave ends up
 // waiting for one load at a time).  B operands are ds_read_b128 from LDS rows
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   constexpr int ROWB = KSL * 2 + 32;       // padded LDS row (bytes)
   constexpr int XBUF = ROWS * ROWB;
   constexpr int G = KSL / 32 / U;          // register groups per phase (8, 4 or 2)
-  constexpr int D = W8 ? 8 : 4;            // ring depth: fp8 groups are half the bytes, so twice as many are in flight
+  constexpr int D = 2;                     // ring depth: one group computing, one in flight; deeper rings measured no faster (more outstanding requests only lengthen the memory queues) and cost registers
   constexpr int PU = G >= D ? 1 : D / G;   // phases per main-loop iteration: ring slots stay compile-time
   const int ubase = phases_total / static_cast<int>(gridDim.y), urem = phases_total % static_cast<int>(gridDim.y);
   const int P = ubase + (static_cast<int>(blockIdx.y) < urem ? 1 : 0);
@@ -536,7 +536,7 @@ static bool launch_geometry(int mt, int nw, int ksl, int epi, bool norm, dim3 gr
     return launch_cfg<T, MT_, NW_, KSL_, FUSED_>(epi, norm, grid, s, MI355_LT_ARGS, fa);
   MI355_LT_GEOM(1, 8, 1024, true) MI355_LT_GEOM(1, 4, 512, true) MI355_LT_GEOM(1, 4, 1024, false) MI355_LT_GEOM(1, 8, 512, false)
   MI355_LT_GEOM(2, 8, 1024, true) MI355_LT_GEOM(2, 4, 512, true) MI355_LT_GEOM(2, 4, 1024, false) MI355_LT_GEOM(2, 8, 512, false)
-  MI355_LT_GEOM(4, 8, 512, true) MI355_LT_GEOM(4, 4, 256, true)
+  MI355_LT_GEOM(4, 8, 512, true) MI355_LT_GEOM(4, 4, 256, true) MI355_LT_GEOM(4, 8, 256, true)
   MI355_LT_GEOM(8, 8, 256, true)
 #undef MI355_LT_GEOM
   return false;
@@ -613,7 +613,7 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
                                              x_stride, y_stride, tiles_total, phases, fa);
   MI355_REQUIRE(ok, MI355_ERR_UNSUPPORTED,
                 "%s: no kernel for M %d with tiles_per_wg %d, epilogue %d%s (M <= 32: 4/8/104/108, fused and fp8 "
-                "forms 8/104; M <= 64: 8/104; M <= 128: 8)", name, M, tiles_per_wg, epilogue,
+                "forms 8/104; M <= 64: 8/104/108; M <= 128: 8)", name, M, tiles_per_wg, epilogue,
                 norm ? " + norm prologue" : "");
   return check_launch(name);
 }

@@ -428,7 +428,7 @@ def linear_tiled_candidates(N: int, K: int, split_k: bool, M: int = 32):
         return []
     out = [first]
     tiles_total = (N + 15) // 16
-    for tiles in ((8, 104) if M <= 64 else (8,)):
+    for tiles in ((8, 104) if M <= 32 else (8, 104, 108) if M <= 64 else (8,)):
         ksl = tiled_slice_width(M, tiles)
         if K % ksl:
             continue
