@@ -284,8 +284,10 @@ int32_t mi355_linear_decode(void* y, int64_t y_stride, const void* x,
 /*
  * Fragment-tiled weights for mi355_linear_tiled.  A row-major [N, K] matrix is
  * re-laid once (at model load) into 1 KB blocks of 16 rows x 32 k stored in the
- * register order of the MFMA operand, blocks ordered [tile][k-step]; rows are
- * zero-padded to a multiple of 16.  mi355_tiled_weight_elems gives the element
+ * register order of the MFMA operand, blocks ordered [k-step / 4][tile][k-step % 4]
+ * (K a multiple of 128): the waves of a launch, one per tile and all near the
+ * same k, then read one contiguous region together; rows are zero-padded to a
+ * multiple of 16.  mi355_tiled_weight_elems gives the element
  * count of the destination.  With interleave_halves != 0 the 16-row tiles
  * alternate between the first and the second half of the rows (gate / up of a
  * fused SwiGLU projection), which lets the GEMM epilogue apply the gate.
@@ -396,8 +398,9 @@ int32_t mi355_linear_tiled_fused(void* y, int64_t y_stride, float* partial,
  * vllm_templates.py:75-76): OCP e4m3fn weights with one fp32 scale per weight row,
  * scale = max|row| / 448, q = fp8_rne(w / scale), laid out in 1 KB blocks of 16
  * rows x 64 k in MFMA operand order (a lane's 16 bytes are its elements of two
- * consecutive k-steps).  mi355_tile_weights_fp8 quantises and tiles a row-major
- * 16-bit [N, K] matrix (K % 64 == 0) into dst (mi355_tiled_weight_fp8_bytes(N, K)
+ * consecutive k-steps), blocks ordered [k / 128][tile][(k / 64) % 2] like the 16-bit
+ * tiling.  mi355_tile_weights_fp8 quantises and tiles a row-major
+ * 16-bit [N, K] matrix (K % 128 == 0) into dst (mi355_tiled_weight_fp8_bytes(N, K)
  * bytes) and writes the scales to scale_tiled (fp32 [ceil(N/16) * 16], in the row
  * order of the tiles, so with interleave_halves gate and up rows alternate tile
  * by tile).

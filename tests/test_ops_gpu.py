@@ -855,11 +855,12 @@ def test_linear_tiled_uneven_k_split(ops, M, N, K, tiles, groups, unit):
 # fp8 (e4m3fn) weight-only decode GEMM
 # --------------------------------------------------------------------------- #
 def _untile_fp8(qbytes, N, K):
-    """[tiles][K/64][lane][16] bytes -> [tiles*16, K] codes (lane (i, h): bytes 0-7 are row i's
-    k = 64p + 8h + j, bytes 8-15 its k = 64p + 32 + 8h + j)."""
+    """[K/128][tiles][2][lane][16] bytes -> [tiles*16, K] codes (1 KB blocks of 16 rows x 64 k ordered
+    k group, tile, pair in group; lane (i, h): bytes 0-7 are row i's k = 64p + 8h + j, bytes 8-15 its
+    k = 64p + 32 + 8h + j)."""
     tiles = (N + 15) // 16
-    b = qbytes.reshape(tiles, K // 64, 4, 16, 2, 8)          # tile, pair, h, i, half, j
-    return b.transpose(0, 3, 1, 4, 2, 5).reshape(tiles * 16, K)
+    b = qbytes.reshape(K // 128, tiles, 2, 4, 16, 2, 8)      # k group, tile, pair, h, i, half, j
+    return b.transpose(1, 4, 0, 2, 5, 3, 6).reshape(tiles * 16, K)
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])

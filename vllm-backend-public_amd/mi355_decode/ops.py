@@ -447,7 +447,7 @@ def tile_weights(weight: torch.Tensor, interleave_halves: bool = False) -> torch
     N, K = weight.shape
     n = int(lib.mi355_tiled_weight_elems(N, K))
     if n == 0:
-        raise ValueError(f"K {K} must be a multiple of 32")
+        raise ValueError(f"K {K} must be a multiple of 128")
     out = torch.empty(n, dtype=weight.dtype, device=weight.device)
     check(lib.mi355_tile_weights(out.data_ptr(), weight.data_ptr(), N, K, int(bool(interleave_halves)), _stream()))
     return out
@@ -555,7 +555,7 @@ def tile_weights_fp8(weight: torch.Tensor, interleave_halves: bool = False):
     N, K = weight.shape
     n = int(lib.mi355_tiled_weight_fp8_bytes(N, K))
     if n == 0:
-        raise ValueError(f"K {K} must be a multiple of 64")
+        raise ValueError(f"K {K} must be a multiple of 128")
     q = torch.empty(n, dtype=torch.uint8, device=weight.device)
     scale = torch.empty((N + 15) // 16 * 16, dtype=torch.float32, device=weight.device)
     check(lib.mi355_tile_weights_fp8(q.data_ptr(), scale.data_ptr(), weight.data_ptr(), N, K,
