@@ -118,6 +118,99 @@ __global__ __launch_bounds__(kThreads) void rms_norm_kernel(
   }
 }
 
+// The PART + ADD form for the slab counts and widths of the decode step, with every load of the
+// row -- SLABS x NV slab vectors, the residual, the bias, the norm weight -- issued before the
+// first value is used.  The generic kernel walks the slabs in a run-time loop, one dependent
+// round trip to memory per slab; this one pays one.  A thread owns NV 8-element vectors of the
+// row (vector indices beyond the row are clamped: loaded, never stored).  Same arithmetic, in the
+// same order, as the generic kernel.
+// SLABS == 0: x is a 16-bit tensor (the plain fused add + norm), loaded the same way.
+template <typename T, int SLABS, int NV>
+__global__ __launch_bounds__(kThreads) void rms_norm_slabs_kernel(
+    uint16_t* out, uint16_t* residual, const uint16_t* __restrict__ weight, int hidden,
+    int64_t out_stride, int64_t res_stride, float eps, const float* __restrict__ partial, int64_t slab_stride,
+    const uint16_t* __restrict__ bias, const uint16_t* x16, int64_t x_stride) {
+  const int64_t row = blockIdx.x;
+  const int nvec = hidden >> 3;
+  const float* pr = SLABS > 0 ? partial + row * hidden : nullptr;
+  const uint4* xr = SLABS > 0 ? nullptr : reinterpret_cast<const uint4*>(x16 + row * x_stride);
+  uint4* rr = reinterpret_cast<uint4*>(residual + row * res_stride);
+  uint4* orow = reinterpret_cast<uint4*>(out + row * out_stride);
+  const uint4* wv = reinterpret_cast<const uint4*>(weight);
+  // a null bias reads the norm weight instead and is multiplied away: no branch around a load
+  const uint4* bv = reinterpret_cast<const uint4*>(bias != nullptr ? bias : weight);
+  const float has_bias = bias != nullptr ? 1.f : 0.f;
+
+  float4 a[NV][SLABS > 0 ? SLABS : 1][2];
+  uint4 res[NV], wr[NV], br[NV], xv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = min(static_cast<int>(threadIdx.x) + i * kThreads, nvec - 1);
+#pragma unroll
+    for (int s = 0; s < SLABS; ++s) {
+      const float4* p = reinterpret_cast<const float4*>(pr + s * slab_stride + 8 * v);
+      a[i][s][0] = p[0];
+      a[i][s][1] = p[1];
+    }
+    if (SLABS == 0) xv[i] = xr[v];
+    res[i] = rr[v];
+    br[i] = bv[v];
+    wr[i] = wv[v];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  float f[NV][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = static_cast<int>(threadIdx.x) + i * kThreads;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[i][j] = 0.f;
+#pragma unroll
+    for (int s = 0; s < SLABS; ++s) {
+      f[i][0] += a[i][s][0].x; f[i][1] += a[i][s][0].y; f[i][2] += a[i][s][0].z; f[i][3] += a[i][s][0].w;
+      f[i][4] += a[i][s][1].x; f[i][5] += a[i][s][1].y; f[i][6] += a[i][s][1].z; f[i][7] += a[i][s][1].w;
+    }
+    float bb[8], r[8];
+    unpack8<T>(br[i], bb);
+    unpack8<T>(res[i], r);
+    if (SLABS == 0) {
+      unpack8<T>(xv[i], f[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[i][j] = round_f<T>(f[i][j] + r[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (has_bias != 0.f) f[i][j] += bb[j];
+        f[i][j] = round_f<T>(round_f<T>(f[i][j]) + r[j]);
+      }
+    }
+    if (v < nvec) {
+      rr[v] = pack8<T>(f[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += f[i][j] * f[i][j];
+    }
+  }
+
+  __shared__ float part[kThreads / 64];
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  float total = 0.f;
+#pragma unroll
+  for (int i = 0; i < kThreads / 64; ++i) total += part[i];
+  const float inv = 1.0f / sqrtf(total / static_cast<float>(hidden) + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = static_cast<int>(threadIdx.x) + i * kThreads;
+    float w[8], y[8];
+    unpack8<T>(wr[i], w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = round_f<T>(f[i][j] * inv) * w[j];
+    if (v < nvec) orow[v] = pack8<T>(y);
+  }
+}
+
 template <bool ADD, bool PART = false>
 static int32_t launch(void* out, const void* x, void* residual, const void* weight,
                       int64_t num_tokens, int32_t hidden, int64_t x_stride, int64_t out_stride,
@@ -155,6 +248,35 @@ static int32_t launch(void* out, const void* x, void* residual, const void* weig
   auto* r = static_cast<uint16_t*>(residual);
   auto* w = static_cast<const uint16_t*>(weight);
   auto* bp = static_cast<const uint16_t*>(bias);
+  // out == x is allowed: a thread reads its vectors of x before it writes the same vectors of out
+  if (ADD && (hidden >> 3) <= 4 * kThreads &&
+      (!PART || num_slabs == 1 || num_slabs == 2 || num_slabs == 4 || num_slabs == 8)) {
+    const int nv = ((hidden >> 3) + kThreads - 1) / kThreads;   // 1..4 vectors per thread
+    if (!PART) num_slabs = 0;
+#define MI355_RMS_SLABS(TT, SS, NN)                                                                          \
+  hipLaunchKernelGGL((rms_norm_slabs_kernel<TT, SS, NN>), grid, block, 0, s, o, r, w, hidden, out_stride,     \
+                     res_stride, eps, partial, slab_stride, bp, PART ? nullptr : xi, x_stride)
+#define MI355_RMS_SLABS_NV(TT, SS)                                                                           \
+  do {                                                                                                       \
+    if (nv == 1) MI355_RMS_SLABS(TT, SS, 1);                                                                 \
+    else if (nv == 2) MI355_RMS_SLABS(TT, SS, 2);                                                            \
+    else if (nv == 3) MI355_RMS_SLABS(TT, SS, 3);                                                            \
+    else MI355_RMS_SLABS(TT, SS, 4);                                                                         \
+  } while (0)
+#define MI355_RMS_SLABS_T(TT)                                                                                \
+  do {                                                                                                       \
+    if (num_slabs == 0) MI355_RMS_SLABS_NV(TT, 0);                                                           \
+    else if (num_slabs == 1) MI355_RMS_SLABS_NV(TT, 1);                                                      \
+    else if (num_slabs == 2) MI355_RMS_SLABS_NV(TT, 2);                                                      \
+    else if (num_slabs == 4) MI355_RMS_SLABS_NV(TT, 4);                                                      \
+    else MI355_RMS_SLABS_NV(TT, 8);                                                                          \
+  } while (0)
+    if (dtype == MI355_BF16) MI355_RMS_SLABS_T(BF16); else MI355_RMS_SLABS_T(F16);
+#undef MI355_RMS_SLABS_T
+#undef MI355_RMS_SLABS_NV
+#undef MI355_RMS_SLABS
+    return check_launch(name);
+  }
 #define MI355_RMS_LAUNCH(TT, CC)                                                                         \
   hipLaunchKernelGGL((rms_norm_kernel<TT, ADD, CC, PART>), grid, block, 0, s, o, xi, r, w, hidden, x_stride, \
                      out_stride, res_stride, eps, partial, num_slabs, slab_stride, bp)
