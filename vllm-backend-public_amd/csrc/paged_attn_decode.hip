@@ -45,6 +45,14 @@ namespace mi355 {
 constexpr int kDecodeThreads = 256;
 constexpr int kDecodeWaves = kDecodeThreads / 64;
 constexpr int kStep = 32;  // tokens per wave step (two 16-token pages)
+// Register sets of K/V tiles per wave: the loads of a wave's next step are in flight while it
+// computes one (measured at contexts 129-255: 13.6 vs 15.2 us; three sets were slower again).
+constexpr int kStages = 2;
+
+template <int KS, int NT>
+struct KVRegs {
+  uint4 ka[KS], kb[KS], vf[NT];
+};
 
 struct RopeArgs {             // FUSE != 0
   const float* partial;       // FUSE == 2: [num_slabs][num_seqs][width] fp32
@@ -164,7 +172,10 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
 
   const int seq = blockIdx.x, kvh = blockIdx.y, split = blockIdx.z;
   const int group = num_heads / num_kv_heads;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  // wave-uniform by construction; saying so keeps the block-table lookups of the main loop on the
+  // scalar unit (a vector lookup would have to wait for vmcnt(0), i.e. for every K/V load in flight)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, h = lane >> 4;
 
   // Without splits the block-table entries of a wave's first step do not depend on the context
@@ -190,9 +201,10 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
   const int last_blk_idx = ctx > 0 ? (ctx - 1) / BS : 0;
   const int koff = ((c >> 2) & 1) * 8 + (c & 3);  // token row inside the page for tile "a"
 
-  // ---- loads of one 32-token step: K tiles a/b, then the V tiles
-  uint4 ka[KS], kb[KS], vf[NT];
-  auto issue_page_loads = [&](int blk0, int blk1) {
+  // ---- loads of one 32-token step: K tiles a/b, then the V tiles.  kStages register sets: a wave
+  // keeps the loads of its next kStages - 1 steps in flight while it computes one.
+  KVRegs<KS, NT> kv[kStages];
+  auto issue_page_loads = [&](KVRegs<KS, NT>& r, int blk0, int blk1) {
     blk0 = min(max(blk0, 0), num_blocks - 1);
     blk1 = min(max(blk1, 0), num_blocks - 1);
     const int kblk = (c & 8) ? blk1 : blk0;
@@ -200,28 +212,27 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
         k_cache + ((static_cast<int64_t>(kblk) * num_kv_heads + kvh) * BS + koff) * D + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      ka[ks] = *reinterpret_cast<const uint4*>(kp + 32 * ks);
-      kb[ks] = *reinterpret_cast<const uint4*>(kp + 4 * D + 32 * ks);
+      r.ka[ks] = *reinterpret_cast<const uint4*>(kp + 32 * ks);
+      r.kb[ks] = *reinterpret_cast<const uint4*>(kp + 4 * D + 32 * ks);
     }
     const int vblk = (h & 2) ? blk1 : blk0;
     const uint16_t* vp =
         v_cache + ((static_cast<int64_t>(vblk) * num_kv_heads + kvh) * D + c) * BS + 8 * (h & 1);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) vf[n] = *reinterpret_cast<const uint4*>(vp + n * 16 * BS);
+    for (int n = 0; n < NT; ++n) r.vf[n] = *reinterpret_cast<const uint4*>(vp + n * 16 * BS);
   };
-  auto issue_loads = [&](int tb) {
+  // Always issued, never inside a branch (a load inside a branch makes the compiler drain the load
+  // queue at the join): a step beyond the wave's range reads the context's last pages, which the
+  // cache holds, and is never used.
+  auto issue_loads = [&](KVRegs<KS, NT>& r, int tb) {
     const int bi = min(tb / BS, last_blk_idx);
-    issue_page_loads(bt[bi], bt[min(bi + 1, last_blk_idx)]);
+    issue_page_loads(r, bt[bi], bt[min(bi + 1, last_blk_idx)]);
   };
   int tb = t_begin + kStep * wave;
-  // The loads of the wave's first step are in flight while the query is prepared.  They are
-  // unconditional (a wave without tokens loads a valid page it never uses): a load inside a
-  // branch makes the compiler drain the load queue at the join, which would put the page loads
-  // and the query's loads one after the other.
   if (!SPLIT) {
-    issue_page_loads(e0, e1);
+    issue_page_loads(kv[0], e0, e1);
   } else {
-    issue_loads(tb);
+    issue_loads(kv[0], tb);
   }
 
   // Q fragments (B operand): column c = head within the group
@@ -308,18 +319,18 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
 #pragma unroll
   for (int n = 0; n < NT; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  while (tb < t_end) {
+  auto step = [&](KVRegs<KS, NT>& kvr, int tb) {
     if (FUSE != 0 && t_new >= tb && t_new < tb + kStep) {
       // the new token's k row / v column come from registers, whatever the pages held
       const int r = t_new - tb;
       const int ta = 16 * (c >> 3) + koff;           // token of this lane's row in tile a; tile b: + 4
       if (r == ta) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) ka[ks] = knew[ks];
+        for (int ks = 0; ks < KS; ++ks) kvr.ka[ks] = knew[ks];
       }
       if (r == ta + 4) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) kb[ks] = knew[ks];
+        for (int ks = 0; ks < KS; ++ks) kvr.kb[ks] = knew[ks];
       }
       if ((r >> 3) == h) {                           // this lane's 8 tokens are 8h .. 8h + 7
         const int j = r & 7;
@@ -327,11 +338,11 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const uint32_t ins = static_cast<uint32_t>(vnew[n]) << ((j & 1) * 16);
-          uint32_t w[4] = {vf[n].x, vf[n].y, vf[n].z, vf[n].w};
+          uint32_t w[4] = {kvr.vf[n].x, kvr.vf[n].y, kvr.vf[n].z, kvr.vf[n].w};
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (e == (j >> 1)) w[e] = (w[e] & keep) | ins;
-          vf[n] = make_uint4(w[0], w[1], w[2], w[3]);
+          kvr.vf[n] = make_uint4(w[0], w[1], w[2], w[3]);
         }
       }
     }
@@ -340,8 +351,8 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
     f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      sa = T::mfma(ka[ks], qf[ks], sa);
-      sb = T::mfma(kb[ks], qf[ks], sb);
+      sa = T::mfma(kvr.ka[ks], qf[ks], sa);
+      sb = T::mfma(kvr.kb[ks], qf[ks], sb);
     }
     // lane (head c, h) now holds tokens tb + 8h + j, j = 0..7 (sa: j<4, sb: j>=4)
     float s[8];
@@ -380,18 +391,29 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
         msk[w] = ((tok0 + 2 * w < t_end) ? 0x0000FFFFu : 0u) | ((tok0 + 2 * w + 1 < t_end) ? 0xFFFF0000u : 0u);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        vf[n].x &= msk[0];
-        vf[n].y &= msk[1];
-        vf[n].z &= msk[2];
-        vf[n].w &= msk[3];
+        kvr.vf[n].x &= msk[0];
+        kvr.vf[n].y &= msk[1];
+        kvr.vf[n].z &= msk[2];
+        kvr.vf[n].w &= msk[3];
       }
     }
     // ---- O^T += V^T . P^T
 #pragma unroll
-    for (int n = 0; n < NT; ++n) o[n] = T::mfma(vf[n], pf, o[n]);
+    for (int n = 0; n < NT; ++n) o[n] = T::mfma(kvr.vf[n], pf, o[n]);
 
-    tb += kStep * kDecodeWaves;
-    if (tb < t_end) issue_loads(tb);
+  };
+#pragma unroll
+  for (int j = 1; j < kStages; ++j) issue_loads(kv[j], tb + j * kStep * kDecodeWaves);
+  __builtin_amdgcn_sched_barrier(0);
+  while (tb < t_end) {
+#pragma unroll
+    for (int j = 0; j < kStages; ++j) {
+      if (tb < t_end) {
+        step(kv[j], tb);
+      }
+      issue_loads(kv[j], tb + kStages * kStep * kDecodeWaves);
+      tb += kStep * kDecodeWaves;
+    }
   }
 
   // column sums live on the 4 lanes (c, h = 0..3)
