@@ -287,7 +287,7 @@ def test_timing_based_choice_of_gemm_form_matches_oracle():
     timed = {k: r.tune_us[(bucket, k)] for k in r.KINDS}
     print(f"bucket {bucket}: (tiled us, library us) {timed} -> {r._modes[bucket]}")
     for k, (tt, tl) in timed.items():
-        assert tt > 0 and tl > 0 and r._modes[bucket][k] == (tt <= tl)
+        assert tt > 0 and tl > 0 and r._modes[bucket][k] == (tt <= 1.05 * tl)
 
 
 @pytest.mark.parametrize("nseq", [40, 72])

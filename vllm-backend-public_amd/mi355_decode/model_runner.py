@@ -357,7 +357,7 @@ class ModelRunner:
                     tl = self._time_launches(lib_fn)
                     self.tune_us[(bucket, k)] = (round(best_us, 2), round(tl, 2))
                     avail[k] = best
-                    mode[k] = best_us <= tl
+                    mode[k] = best_us <= 1.05 * tl          # near-ties stay tiled: the choice should not flip from run to run
             except RuntimeError as exc:                     # timing replays graphs: without them, no choice is made
                 import logging
                 logging.getLogger("mi355_decode").warning(
