@@ -355,7 +355,8 @@ class ModelRunner:
                         best_us = self._time_launches(tiled_form(*best))
                     lib_fn(0)                               # first library call may pick its algorithm
                     tl = self._time_launches(lib_fn)
-                    self.tune_us[(bucket, k)] = (round(best_us, 2), round(tl, 2))
+                    best_us, tl = round(best_us, 2), round(tl, 2)
+                    self.tune_us[(bucket, k)] = (best_us, tl)
                     avail[k] = best
                     mode[k] = best_us <= 1.05 * tl          # near-ties stay tiled: the choice should not flip from run to run
             except RuntimeError as exc:                     # timing replays graphs: without them, no choice is made
