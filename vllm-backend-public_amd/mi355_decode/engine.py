@@ -327,8 +327,7 @@ class LLMEngine:
         # prompt scoring: row r of the packed batch predicts the prompt token after it
         rows, targets, owners = [], [], []
         for i, (seq, start, n) in enumerate(chunks):
-            pk = seq.params.prompt_logprobs
-            if pk is None:
+            if seq.params.prompt_logprobs is None:
                 continue
             if seq.prompt_logprobs is None:
                 seq.prompt_logprobs = [None]
