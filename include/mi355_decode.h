@@ -302,9 +302,11 @@ int32_t mi355_tile_weights(void* dst, const void* src, int32_t N, int32_t K,
  * and each wave streams one 16-row tile of W; x is staged through LDS once per
  * workgroup, one K slice at a time.  tiles_per_wg = 4 or 8 tiles (= waves) per
  * workgroup with wide x slices, or 104 / 108 for the same with narrow slices (two
- * workgroups per CU).  Slice width: 1024 (narrow 512) for M <= 32, halved for
+ * workgroups per CU); 208 / 216 (33..128 rows, epilogues 0-2): every wave streams two
+ * adjacent tiles and uses each x fragment it reads from LDS for both -- 4 waves
+ * with narrow slices / 8 waves with wide ones.  Slice width: 1024 (narrow 512) for M <= 32, halved for
  * M <= 64 and again for M <= 128; K must be a multiple of it.  Built geometries: M <= 32: 4,
- * 8, 104, 108; M <= 64: 8, 104, 108; M <= 128: 8.  k_groups (at most K / slice)
+ * 8, 104, 108; M <= 64: 8, 104, 108, 208, 216; M <= 128: 8, 216.  k_groups (at most K / slice)
  * splits K over workgroups; the slices are dealt to the groups as evenly as they
  * go, K / slice need not be a multiple of k_groups.
  *   epilogue 0: y = round(sum + bias)                       (k_groups == 1)

@@ -703,7 +703,9 @@ def test_linear_tiled_norm_prologue(ops, dtype, M, H, N2, tiles, epi):
 @pytest.mark.parametrize("M,N,K,tiles,groups", [(64, 4096, 4096, 104, 4), (33, 1000, 1024, 8, 1), (64, 6144, 4096, 8, 1),
                                                 (128, 4096, 14336, 8, 7), (100, 1536, 4096, 8, 8), (65, 320, 512, 8, 1),
                                                 (128, 28672, 4096, 8, 1), (48, 4096, 1024, 104, 2),
-                                                (64, 4096, 4096, 108, 4), (40, 1000, 1024, 108, 1), (64, 4736, 3584, 108, 1)])
+                                                (64, 4096, 4096, 108, 4), (40, 1000, 1024, 108, 1), (64, 4736, 3584, 108, 1),
+                                                (64, 4096, 4096, 208, 4), (40, 1000, 1024, 216, 1), (64, 4736, 3584, 208, 1),
+                                                (128, 4096, 14336, 216, 7), (100, 1544, 4096, 216, 8), (65, 336, 512, 216, 1)])
 def test_linear_tiled_up_to_128_rows(ops, dtype, M, N, K, tiles, groups):
     """33..128 rows (more m-tiles per wave, narrower x slices): store, partial slabs and the
     in-launch reduction against the fp64 product; the reduction bit-identical to the slab sum."""
@@ -725,7 +727,7 @@ def test_linear_tiled_up_to_128_rows(ops, dtype, M, N, K, tiles, groups):
         np.testing.assert_allclose(part[g], ref, rtol=1e-4, atol=2e-3)
     y_ref = _slab_sum(part, None, dtype)
     assert (np.abs(y_ref - ref64) <= tol).all()
-    if N % 8 == 0:
+    if N % 8 == 0 and tiles < 200:                                   # the two-tiles-per-wave forms have no in-launch reduction
         counters = torch.zeros(_groups(N, tiles), dtype=torch.int32, device="cuda")
         for _ in range(2):
             y = ops.linear_tiled_fused(xd, wt, N, tiles_per_wg=tiles, k_groups=groups, epilogue=ops.EPI_REDUCE_STORE,
@@ -739,10 +741,15 @@ def test_linear_tiled_swiglu_epilogue_up_to_128_rows(ops, M, F, K):
     rng = rng_for("tiled-silu-rows", M, F, K)
     x, w = grid(rng, (M, K), dtype), grid(rng, (2 * F, K), dtype, 0.05)
     xd = dev(x, dtype)
-    y = host(ops.linear_tiled(xd, ops.tile_weights(dev(w, dtype), interleave_halves=True), 2 * F,
-                              epilogue=ops.EPI_SILU_MUL))
+    wi = ops.tile_weights(dev(w, dtype), interleave_halves=True)
+    y = host(ops.linear_tiled(xd, wi, 2 * F, epilogue=ops.EPI_SILU_MUL))
     gu = ops.linear_tiled(xd, ops.tile_weights(dev(w, dtype)), 2 * F)
     np.testing.assert_array_equal(y, host(ops.silu_and_mul(gu)))
+    # two tiles per wave: the wave holds the gate and the up tile itself; same sums, same bits
+    for tiles in ([208, 216] if M <= 64 else [216]):
+        if K % ops.tiled_slice_width(M, tiles) == 0:
+            y2 = host(ops.linear_tiled(xd, wi, 2 * F, epilogue=ops.EPI_SILU_MUL, tiles_per_wg=tiles))
+            np.testing.assert_array_equal(y2, y)
     ref = R.silu_and_mul(R.linear(x, w, None, dtype), dtype)
     diff = np.abs(y - ref)
     assert (diff <= 4 * ULP[dtype] * np.abs(ref) + 4 * ULP[dtype] * 1e-2).all()
@@ -890,7 +897,8 @@ def test_tile_weights_fp8(ops, dtype, N, K, inter):
                                                      (7, 1000, 1024, 104, 1, True), (64, 3584, 18944, 104, 4, False),
                                                      (128, 4608, 3584, 8, 7, True), (1, 64, 512, 104, 1, False),
                                                      (48, 6144, 4096, 8, 1, True), (64, 3584, 18944, 108, 8, False),
-                                                     (48, 6144, 4096, 108, 1, True)])
+                                                     (48, 6144, 4096, 108, 1, True), (64, 3584, 18944, 208, 8, False),
+                                                     (48, 6144, 4096, 216, 1, True), (128, 4616, 3584, 216, 7, True)])
 def test_linear_tiled_w8(ops, dtype, M, N, K, tiles, groups, bias):
     rng = rng_for("w8", dtype, M, N, K)
     x, w = grid(rng, (M, K), dtype), grid(rng, (N, K), dtype, 0.05)

@@ -391,6 +391,223 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   }
 }
 
+// ---- two tiles per wave (33..128 rows).  At these row counts a k-step of one tile is 4 or 8 MFMAs,
+// each fed by a 1 KB B fragment read from LDS, and with one tile per wave every wave of the
+// workgroup reads the whole x slice again: the LDS reads, not the weight stream, bound the kernel
+// (64 rows: 512 KB of fragments per 256 columns of x per CU).  Here a wave streams TWO adjacent
+// tiles (8 KB of contiguous memory per register group) and uses every fragment for both, which
+// halves the LDS reads per weight byte.  Adjacent tiles are the gate / up pair of an interleaved
+// SwiGLU matrix, so that epilogue needs no exchange between waves.  Epilogues: store, SwiGLU,
+// partial slabs (no norm prologue, no in-launch reduction).
+template <typename T, int MT, int NW, int KSL, int EPI, bool W8>
+__global__ __launch_bounds__(NW * 64) void linear_tiled2_kernel(
+    uint16_t* __restrict__ y, float* __restrict__ partial, const uint16_t* __restrict__ x,
+    const uint16_t* __restrict__ wt, const uint16_t* __restrict__ bias, int M, int N, int K,
+    int64_t x_stride, int64_t y_stride, int tiles_total, int phases_total, const float* __restrict__ w_scale) {
+  constexpr int TPW = 2;
+  constexpr int ROWS = MT * 16;
+  constexpr int U = kTU;
+  constexpr int NT = NW * 64;
+  constexpr int ROWB = KSL * 2 + 32;
+  constexpr int XBUF = ROWS * ROWB;
+  constexpr int G = KSL / 32 / U;
+  constexpr int D = 2;
+  constexpr int PU = G >= D ? 1 : D / G;
+  static_assert((PU * G) % D == 0, "ring slots must repeat every main-loop iteration");
+  static_assert(NT % (KSL / 8) == 0, "a thread must keep one column of the x slice");
+  const int ubase = phases_total / static_cast<int>(gridDim.y), urem = phases_total % static_cast<int>(gridDim.y);
+  const int P = ubase + (static_cast<int>(blockIdx.y) < urem ? 1 : 0);
+  const int p0 = static_cast<int>(blockIdx.y) * ubase + min(static_cast<int>(blockIdx.y), urem);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * XBUF];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, h = lane >> 4;
+  const int tile_raw = (blockIdx.x * NW + wave) * TPW;            // first of the wave's two tiles
+  // both tiles clamped into the matrix; an odd tile count leaves the last wave's second tile a copy (never stored)
+  const int tile0 = min(tile_raw, tiles_total - 1), tile1 = min(tile_raw + 1, tiles_total - 1);
+  const int kgroup = blockIdx.y;
+
+  constexpr int NX = ROWS * (KSL / 8) / NT;
+  typedef unsigned int xvec __attribute__((ext_vector_type(4)));
+  auto x_issue = [&](xvec (&xs)[NX], int p) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int v = i * NT + tid;
+      const int row = v / (KSL / 8), col = v % (KSL / 8);
+      xs[i] = *reinterpret_cast<const xvec*>(x + static_cast<int64_t>(min(row, M - 1)) * x_stride +
+                                             static_cast<int64_t>(p) * KSL + col * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto x_commit = [&](xvec (&xs)[NX], int buf) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int v = i * NT + tid;
+      const int row = v / (KSL / 8), col = v % (KSL / 8);
+      *reinterpret_cast<xvec*>(&lds[buf * XBUF + row * ROWB + col * 16]) = xs[i];
+    }
+  };
+
+  constexpr int LPG = W8 ? U / 2 : U;
+  const int64_t gstride = static_cast<int64_t>(tiles_total) * (LPG * 512);
+  const uint16_t* wbase0 = wt + (static_cast<int64_t>(p0) * G * tiles_total + tile0) * (LPG * 512) + lane * 8;
+  const uint16_t* wbase1 = wt + (static_cast<int64_t>(p0) * G * tiles_total + tile1) * (LPG * 512) + lane * 8;
+  const int groups_total = P * G;
+  auto load_group = [&](uint4 (&wd)[TPW][LPG], int g) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int64_t off = min(g, groups_total - 1) * gstride;
+#pragma unroll
+    for (int u = 0; u < LPG; ++u) {
+      const u32x4 v0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase0 + off + u * 512));
+      wd[0][u] = make_uint4(v0.x, v0.y, v0.z, v0.w);
+    }
+#pragma unroll
+    for (int u = 0; u < LPG; ++u) {
+      const u32x4 v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase1 + off + u * 512));
+      wd[1][u] = make_uint4(v1.x, v1.y, v1.z, v1.w);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto dequant8 = [&](uint32_t lo, uint32_t hi) {
+    return make_uint4(T::fp8x2(lo, false), T::fp8x2(lo, true), T::fp8x2(hi, false), T::fp8x2(hi, true));
+  };
+
+  f32x4 acc[TPW][MT];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](uint4 (&wd)[TPW][LPG], int buf, int g) {
+    const unsigned char* xb = &lds[buf * XBUF + c * ROWB + g * (U * 64) + 16 * h];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      uint4 a[TPW];
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        if (W8) {
+          const uint4 v = wd[j][u / 2];
+          a[j] = (u & 1) ? dequant8(v.z, v.w) : dequant8(v.x, v.y);
+        } else {
+          a[j] = wd[j][u];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const uint4 b = *reinterpret_cast<const uint4*>(xb + u * 64 + m * 16 * ROWB);   // one fragment, both tiles
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) acc[j][m] = T::mfma(a[j], b, acc[j][m]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  uint4 ring[D][TPW][LPG];
+#pragma unroll
+  for (int j = 0; j < D - 1; ++j) load_group(ring[j], j);
+  {
+    xvec xs0[NX];
+    x_issue(xs0, p0);
+    x_commit(xs0, 0);
+  }
+  __syncthreads();
+  for (int p = 0; p < P; p += PU) {
+#pragma unroll
+    for (int pp = 0; pp < PU; ++pp) {
+      const int q = p + pp;
+      if (q >= P) break;
+      const bool more = q + 1 < P;
+      xvec xs[NX];
+      x_issue(xs, p0 + (more ? q + 1 : q));
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        load_group(ring[(pp * G + g + D - 1) % D], q * G + g + D - 1);
+        compute(ring[(pp * G + g) % D], q & 1, g);
+      }
+      if (more) {
+        x_commit(xs, (q + 1) & 1);
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- epilogue: lane holds D[n = 4h + r][m = c] of each m-tile, for both tiles
+  if (W8) {
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      const float4 sc = *reinterpret_cast<const float4*>(w_scale + (j ? tile1 : tile0) * 16 + 4 * h);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        acc[j][m][0] = pin_f32(acc[j][m][0] * sc.x);
+        acc[j][m][1] = pin_f32(acc[j][m][1] * sc.y);
+        acc[j][m][2] = pin_f32(acc[j][m][2] * sc.z);
+        acc[j][m][3] = pin_f32(acc[j][m][3] * sc.w);
+      }
+    }
+  }
+  if (EPI == EPI_SILU_MUL) {           // tile_raw is even: tile0 = gate rows, tile1 = up rows of the same 16 columns
+    if (tile_raw + 1 >= tiles_total) return;
+    const int F = N >> 1;
+    const int j0 = (tile_raw >> 1) * 16 + 4 * h;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int mm = 16 * m + c;
+      if (mm >= M) continue;
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = silu_mul<T>(round_f<T>(acc[0][m][r]), round_f<T>(acc[1][m][r]));
+      uint16_t* yp = y + static_cast<int64_t>(mm) * y_stride + j0;
+      if (j0 + 3 < F) {
+        *reinterpret_cast<uint2*>(yp) = make_uint2(
+            static_cast<uint32_t>(T::from_f(o[0])) | (static_cast<uint32_t>(T::from_f(o[1])) << 16),
+            static_cast<uint32_t>(T::from_f(o[2])) | (static_cast<uint32_t>(T::from_f(o[3])) << 16));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (j0 + r < F) yp[r] = T::from_f(o[r]);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    if (tile_raw + j >= tiles_total) continue;
+    const int n0 = (tile_raw + j) * 16 + 4 * h;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_STORE && bias != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n0 + r < N) bv[r] = T::to_f(bias[n0 + r]);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int mm = 16 * m + c;
+      if (mm >= M) continue;
+      if (EPI == EPI_PARTIAL) {
+        float* pp = partial + (static_cast<int64_t>(kgroup) * M + mm) * N + n0;
+        if (n0 + 3 < N && (N & 3) == 0) {
+          *reinterpret_cast<float4*>(pp) = make_float4(acc[j][m][0], acc[j][m][1], acc[j][m][2], acc[j][m][3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n0 + r < N) pp[r] = acc[j][m][r];
+        }
+      } else {
+        uint16_t* yp = y + static_cast<int64_t>(mm) * y_stride + n0;
+        if (n0 + 3 < N && (y_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0) {
+          *reinterpret_cast<uint2*>(yp) = make_uint2(
+              static_cast<uint32_t>(T::from_f(acc[j][m][0] + bv[0])) | (static_cast<uint32_t>(T::from_f(acc[j][m][1] + bv[1])) << 16),
+              static_cast<uint32_t>(T::from_f(acc[j][m][2] + bv[2])) | (static_cast<uint32_t>(T::from_f(acc[j][m][3] + bv[3])) << 16));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n0 + r < N) yp[r] = T::from_f(acc[j][m][r] + bv[r]);
+        }
+      }
+    }
+  }
+}
+
 // Row-major [N, K] -> fragment-tiled (see the top of the file); rows beyond N are zero.
 // With `interleave_halves` the source rows are first reordered so that 16-row tiles
 // alternate between the first half (gate) and the second half (up) of the matrix.
@@ -552,6 +769,34 @@ static bool launch_geometry(int mt, int nw, int ksl, int epi, bool norm, dim3 gr
   return false;
 }
 
+// Two tiles per wave (tiles_per_wg 208 / 216): epilogues 0-2, 16-bit or fp8 weights, 33..128 rows.
+template <typename T, int MT, int NW, int KSL>
+static bool launch_cfg2(int epi, dim3 grid, hipStream_t s, MI355_LT_PARAMS, const float* w_scale) {
+#define MI355_LT2(EPI_, W8_)                                                                                   \
+  hipLaunchKernelGGL((linear_tiled2_kernel<T, MT, NW, KSL, EPI_, W8_>), grid, dim3(NW * 64), 0, s, MI355_LT_ARGS, \
+                     w_scale)
+  if (w_scale != nullptr) {
+    if (epi == EPI_STORE) { MI355_LT2(EPI_STORE, true); return true; }
+    if (epi == EPI_SILU_MUL) { MI355_LT2(EPI_SILU_MUL, true); return true; }
+    if (epi == EPI_PARTIAL) { MI355_LT2(EPI_PARTIAL, true); return true; }
+  } else {
+    if (epi == EPI_STORE) { MI355_LT2(EPI_STORE, false); return true; }
+    if (epi == EPI_SILU_MUL) { MI355_LT2(EPI_SILU_MUL, false); return true; }
+    if (epi == EPI_PARTIAL) { MI355_LT2(EPI_PARTIAL, false); return true; }
+  }
+#undef MI355_LT2
+  return false;
+}
+
+template <typename T>
+static bool launch_geometry2(int mt, int nw, int ksl, int epi, dim3 grid, hipStream_t s, MI355_LT_PARAMS,
+                             const float* w_scale) {
+  if (mt == 4 && nw == 4 && ksl == 256) return launch_cfg2<T, 4, 4, 256>(epi, grid, s, MI355_LT_ARGS, w_scale);
+  if (mt == 4 && nw == 8 && ksl == 512) return launch_cfg2<T, 4, 8, 512>(epi, grid, s, MI355_LT_ARGS, w_scale);
+  if (mt == 8 && nw == 8 && ksl == 256) return launch_cfg2<T, 8, 8, 256>(epi, grid, s, MI355_LT_ARGS, w_scale);
+  return false;
+}
+
 // Shared argument checks + launch of both entry points.
 static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, float* partial, const void* x,
                                    int64_t x_stride, const void* w_tiled, const void* bias, int32_t M, int32_t N,
@@ -566,11 +811,15 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
   // tiles_per_wg: 4 or 8 tiles (= waves) per workgroup; +100 selects the narrow x slice.  The slice is
   // 1024 (narrow: 512) wide up to 32 rows and halves with every doubling of the rows, so that the
   // double-buffered x image keeps its LDS footprint.
-  const int nw = tiles_per_wg % 100;
-  MI355_REQUIRE((nw == 4 || nw == 8) && (tiles_per_wg == nw || tiles_per_wg == nw + 100), MI355_ERR_INVALID,
-                "%s: tiles_per_wg must be 4, 8, 104 or 108", name);
+  // 208 / 216: two tiles per wave (4 waves with the narrow slice / 8 waves with the wide one), 33..128 rows
+  const bool two = tiles_per_wg == 208 || tiles_per_wg == 216;
+  const int nw = two ? (tiles_per_wg - 200) / 2 : tiles_per_wg % 100;
+  MI355_REQUIRE(two || ((nw == 4 || nw == 8) && (tiles_per_wg == nw || tiles_per_wg == nw + 100)), MI355_ERR_INVALID,
+                "%s: tiles_per_wg must be 4, 8, 104, 108, 208 or 216", name);
   const int mt = M <= 16 ? 1 : M <= 32 ? 2 : M <= 64 ? 4 : 8;
-  const int ksl = (tiles_per_wg >= 100 ? 512 : 1024) / (mt <= 2 ? 1 : mt / 2);
+  const int ksl = ((two ? tiles_per_wg == 208 : tiles_per_wg >= 100) ? 512 : 1024) / (mt <= 2 ? 1 : mt / 2);
+  MI355_REQUIRE(!two || (M > 32 && !norm && !reduce), MI355_ERR_UNSUPPORTED,
+                "%s: two tiles per wave (tiles_per_wg %d) is built for 33..128 rows and epilogues 0-2", name, tiles_per_wg);
   MI355_REQUIRE(N > 0 && K > 0 && K % ksl == 0, MI355_ERR_UNSUPPORTED,
                 "%s: K %d must be a multiple of the x slice %d (M %d)", name, K, ksl, M);
   MI355_REQUIRE(fa.w_scale == nullptr || (aligned16(fa.w_scale) && epilogue <= EPI_PARTIAL), MI355_ERR_INVALID,
@@ -610,20 +859,27 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
                   "%s: SwiGLU epilogue needs N %% 32 == 0 and no bias", name);
   if (M == 0) return MI355_OK;
   const int tiles_total = (N + 15) / 16;
-  dim3 grid((tiles_total + nw - 1) / nw, k_groups);
+  const int tiles_wg = two ? 2 * nw : nw;
+  dim3 grid((tiles_total + tiles_wg - 1) / tiles_wg, k_groups);
   hipStream_t s = static_cast<hipStream_t>(stream);
   auto* yp = static_cast<uint16_t*>(y);
   auto* xp = static_cast<const uint16_t*>(x);
   auto* wp = static_cast<const uint16_t*>(w_tiled);
   auto* bp = static_cast<const uint16_t*>(bias);
-  const bool ok = dtype == MI355_BF16
-                      ? launch_geometry<BF16>(mt, nw, ksl, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K,
-                                              x_stride, y_stride, tiles_total, phases, fa)
-                      : launch_geometry<F16>(mt, nw, ksl, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K,
-                                             x_stride, y_stride, tiles_total, phases, fa);
+  bool ok;
+  if (two)
+    ok = dtype == MI355_BF16 ? launch_geometry2<BF16>(mt, nw, ksl, epilogue, grid, s, yp, partial, xp, wp, bp, M, N, K,
+                                                      x_stride, y_stride, tiles_total, phases, fa.w_scale)
+                             : launch_geometry2<F16>(mt, nw, ksl, epilogue, grid, s, yp, partial, xp, wp, bp, M, N, K,
+                                                     x_stride, y_stride, tiles_total, phases, fa.w_scale);
+  else
+    ok = dtype == MI355_BF16 ? launch_geometry<BF16>(mt, nw, ksl, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K,
+                                                     x_stride, y_stride, tiles_total, phases, fa)
+                             : launch_geometry<F16>(mt, nw, ksl, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K,
+                                                    x_stride, y_stride, tiles_total, phases, fa);
   MI355_REQUIRE(ok, MI355_ERR_UNSUPPORTED,
                 "%s: no kernel for M %d with tiles_per_wg %d, epilogue %d%s (M <= 32: 4/8/104/108, fused and fp8 "
-                "forms 8/104; M <= 64: 8/104/108; M <= 128: 8)", name, M, tiles_per_wg, epilogue,
+                "forms 8/104; M <= 64: 8/104/108/208/216; M <= 128: 8/216)", name, M, tiles_per_wg, epilogue,
                 norm ? " + norm prologue" : "");
   return check_launch(name);
 }

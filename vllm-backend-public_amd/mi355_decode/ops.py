@@ -380,7 +380,13 @@ LINEAR_TILED_MAX_M = 128
 def tiled_slice_width(M: int, tiles_per_wg: int) -> int:
     """K slice of x a workgroup of linear_tiled stages at a time."""
     mt = 1 if M <= 16 else 2 if M <= 32 else 4 if M <= 64 else 8
-    return (512 if tiles_per_wg >= 100 else 1024) // (1 if mt <= 2 else mt // 2)
+    narrow = tiles_per_wg in (104, 108, 208)      # 216 (two tiles per wave, 8 waves) stages the wide slice
+    return (512 if narrow else 1024) // (1 if mt <= 2 else mt // 2)
+
+
+def tiles_per_workgroup(tiles_per_wg: int) -> int:
+    """Weight tiles one workgroup covers for a tiles_per_wg code (208 / 216: two tiles per wave)."""
+    return {208: 8, 216: 16}.get(tiles_per_wg, tiles_per_wg % 100)
 
 
 def plan_linear_tiled(N: int, K: int, split_k: bool, M: int = 32):
@@ -421,18 +427,18 @@ def plan_linear_tiled(N: int, K: int, split_k: bool, M: int = 32):
 def linear_tiled_candidates(N: int, K: int, split_k: bool, M: int = 32):
     """Every (tiles_per_wg, k_groups) worth timing for linear_tiled on an [N, K] weight and M rows:
     both workgroup shapes that every kernel form (fp8, fused epilogues) is built for, K split into
-    1, 2, 4 or 8 groups when the caller can take partial sums, kept if the launch has between 64
-    and 1024 workgroups.  plan_linear_tiled's choice comes first."""
+    1, 2, 4 or 8 groups when the caller can take partial sums, beyond 32 rows also the forms with
+    two tiles per wave (208 / 216), kept if the launch has between 64 and 1024 workgroups.  plan_linear_tiled's choice comes first."""
     first = plan_linear_tiled(N, K, split_k, M)
     if first is None:
         return []
     out = [first]
     tiles_total = (N + 15) // 16
-    for tiles in ((8, 104) if M <= 32 else (8, 104, 108) if M <= 64 else (8,)):
+    for tiles in ((8, 104) if M <= 32 else (8, 104, 108, 208, 216) if M <= 64 else (8, 216)):
         ksl = tiled_slice_width(M, tiles)
         if K % ksl:
             continue
-        wgs = -(-tiles_total // (tiles % 100))
+        wgs = -(-tiles_total // tiles_per_workgroup(tiles))
         for g in ((1, 2, 4, 8) if split_k else (1,)):
             if g <= K // ksl and 64 <= wgs * g <= 1024 and (tiles, g) not in out:
                 out.append((tiles, g))
