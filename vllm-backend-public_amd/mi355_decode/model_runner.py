@@ -1,16 +1,17 @@
-"""One model step on one GPU: embed -> L x [norm, qkv, rope+kv-store, paged
-attention, o-proj (+all-reduce under TP), norm, gate_up, SwiGLU, down] -> norm ->
-lm_head -> greedy token.
+"""One model step on one GPU: embed -> L x [norm, qkv, rope + kv-store + paged attention (one
+kernel at decode), o-proj (+all-reduce under TP), norm, gate_up + SwiGLU, down (+all-reduce when
+the MLP is sharded)] -> norm -> lm_head -> greedy token (a key max-reduce when the lm_head is
+sharded over the vocabulary).
 
-The hot operators go through the C ABI (mi355_decode.ops -> libmi355_decode.so).
-Decode steps of up to 32 sequences on one GPU run their per-layer linear layers
-through the weight-streaming GEMM on fragment-tiled weight copies (K-split layers
-hand fp32 partial sums to the norm / rotary kernels, the SwiGLU gate is applied in
-the gate_up epilogue); larger batches, prefill and the lm_head use library GEMMs on
-the row-major weights.  PyTorch only owns memory, streams and the process group.  The decode step works on statically allocated
-buffers and is captured once per batch-size bucket into a HIP graph (a decode
-step is ~300 short kernels; replay removes the per-launch host cost); prefill
-runs eagerly.
+The hot operators go through the C ABI (mi355_decode.ops -> libmi355_decode.so).  Decode steps of
+up to 128 sequences can run every linear layer through the weight-streaming GEMM on fragment-tiled
+weight copies (K-split layers hand fp32 partial sums to the norm / attention kernels, the SwiGLU
+gate is applied in the gate_up epilogue); which projections do, and in which geometry, is timed
+against the library GEMM once per batch-size class (tune).  Larger batches and prefill use library
+GEMMs on the row-major weights.  PyTorch only owns memory, streams and the process group.  The
+decode step works on statically allocated buffers and is captured once per batch-size bucket into
+a HIP graph (a decode step is ~230 short kernels; replay removes the per-launch host cost);
+prefill runs eagerly.
 """
 from __future__ import annotations
 
