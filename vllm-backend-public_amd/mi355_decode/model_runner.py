@@ -23,7 +23,7 @@ from typing import Optional
 import torch
 
 from . import ops
-from ._lib import BLOCK_SIZE
+from ._lib import BLOCK_SIZE, Mi355Error
 from .config import ModelConfig
 from .weights import ModelWeights
 
@@ -349,7 +349,10 @@ class ModelRunner:
                     for cand in ops.linear_tiled_candidates(n, kk, split, b):
                         if k == "qkv" and cand[1] > self.QKV_MAX_SLABS:
                             continue
-                        us = self._time_launches(tiled_form(*cand))
+                        try:
+                            us = self._time_launches(tiled_form(*cand))
+                        except Mi355Error:                  # no kernel of this form for the code (e.g. fp8 with 108)
+                            continue
                         if best_us is None or us < 0.98 * best_us:      # the planner's own choice unless clearly beaten
                             best, best_us = cand, us
                     if best_us is None:

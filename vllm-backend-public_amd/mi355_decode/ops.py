@@ -428,13 +428,15 @@ def linear_tiled_candidates(N: int, K: int, split_k: bool, M: int = 32):
     """Every (tiles_per_wg, k_groups) worth timing for linear_tiled on an [N, K] weight and M rows:
     both workgroup shapes that every kernel form (fp8, fused epilogues) is built for, K split into
     1, 2, 4 or 8 groups when the caller can take partial sums, beyond 32 rows also the forms with
-    two tiles per wave (208 / 216), kept if the launch has between 64 and 1024 workgroups.  plan_linear_tiled's choice comes first."""
+    two tiles per wave (208 / 216), kept if the launch has between 64 and 1024 workgroups.  Not
+    every form exists for every code (fp8 at up to 32 rows: 8 and 104 only): the caller skips a
+    candidate the library refuses.  plan_linear_tiled's choice comes first."""
     first = plan_linear_tiled(N, K, split_k, M)
     if first is None:
         return []
     out = [first]
     tiles_total = (N + 15) // 16
-    for tiles in ((8, 104) if M <= 32 else (8, 104, 108, 208, 216) if M <= 64 else (8, 216)):
+    for tiles in ((8, 104, 108) if M <= 32 else (8, 104, 108, 208, 216) if M <= 64 else (8, 216)):
         ksl = tiled_slice_width(M, tiles)
         if K % ksl:
             continue
