@@ -113,6 +113,8 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
     runner = ModelRunner(cfg, weights, dtype, device, num_blocks, args.max_num_seqs, max_model_len,
                          tp_rank=rank, tp_size=tp, tp_group=group, use_graphs=graphs,
                          decode_splits=decode_splits, weight_fp8=(args.quantization or "").lower() == "fp8")
+    if os.environ.get("MI355_LAZY_TUNE", "0") != "1":
+        runner.warm_up()                              # every rank, same order: the choices are broadcast
     log.info("tensor-parallel rank %d of %d on %s: %d layers, MLP %s, lm_head %s, %d KV pages, HIP graphs %s",
              rank, tp, device, len(weights.layers), "sharded" if shard_mlp else "whole",
              "sharded" if shard_vocab else "whole", num_blocks, "on" if graphs else "off")

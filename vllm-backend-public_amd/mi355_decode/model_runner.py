@@ -385,6 +385,19 @@ class ModelRunner:
         self._modes[bucket] = mode
         return mode
 
+    def warm_up(self) -> None:
+        """Makes the timed choices (tune) for every kernel row class a decode batch of this runner
+        can fall in, at start-up instead of inside the first request that reaches the class.  The
+        step inputs are left as they were; HIP graphs are still captured on first use."""
+        if self.tiled is None or self.tiled_policy != "auto":
+            return
+        done = set()
+        for bucket in reversed(self.buckets):             # the largest bucket of each class stands for it
+            cls = self._row_class(bucket)
+            if bucket <= ops.LINEAR_TILED_MAX_M and cls not in done:
+                done.add(cls)
+                self.tune(bucket)
+
     def _decode_layers(self, b: int, slots, bt, ctx, splits) -> None:
         """All decoder layers + the final norm for b decode tokens held in self.resid[:b]; leaves the
         normed hidden state in self.x[:b].  Each projection runs as the tiled kernel or as a library
