@@ -71,7 +71,7 @@ def main():
         for shard in (False, True):
             for tiled in (True, False, None):
                 ms, used, tuned = step_ms(cfg, tp, batch, a.ctx, shard, tiled, L)
-                if tiled is not False and used == "-----":
+                if tiled is True and used == "-----":
                     continue                              # no tiled kernels for this row count: same as library
                 print(json.dumps({"model": a.model, "tp": tp, "batch": batch, "layers": L, "mlp_and_vocab_sharded": shard,
                                   "gemms": {True: "tiled", False: "library", None: "timed choice"}[tiled],

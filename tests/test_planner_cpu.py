@@ -1,0 +1,45 @@
+"""Host-side geometry planning of the tiled decode GEMM (no GPU needed): the planner's choice
+and the candidate list the tuner times must only name geometries the library builds, with K
+splits the consumers can take."""
+import pytest
+
+from mi355_decode import ops
+
+SHAPES = [  # N, K, split_k: the projections of the benchmark models and of their tensor-parallel slices
+    (6144, 4096, True), (4096, 4096, True), (28672, 4096, False), (4096, 14336, True), (128256, 4096, False),
+    (4608, 3584, True), (3584, 3584, True), (37888, 3584, False), (3584, 18944, True), (152064, 3584, False),
+    (1280, 8192, True), (8192, 1024, True), (7168, 8192, False), (16032, 4096, False), (1536, 4096, True),
+]
+BUILT = {16: {4, 8, 104, 108}, 32: {4, 8, 104, 108}, 64: {8, 104, 108, 208, 216}, 128: {8, 216}}
+
+
+@pytest.mark.parametrize("M", [1, 16, 17, 32, 33, 64, 65, 128])
+@pytest.mark.parametrize("N,K,split", SHAPES)
+def test_candidates_are_built_geometries(M, N, K, split):
+    cls = 16 if M <= 16 else 32 if M <= 32 else 64 if M <= 64 else 128
+    plan = ops.plan_linear_tiled(N, K, split, M)
+    cands = ops.linear_tiled_candidates(N, K, split, M)
+    if plan is None:
+        assert cands == []
+        return
+    assert cands[0] == plan and len(set(cands)) == len(cands)
+    for tiles, groups in cands:
+        assert tiles in BUILT[cls]
+        ksl = ops.tiled_slice_width(M, tiles)
+        assert K % ksl == 0 and 1 <= groups <= min(K // ksl, 8)
+        assert split or groups == 1
+        assert ops.tiles_per_workgroup(tiles) in (4, 8, 16)
+
+
+def test_rows_beyond_the_kernels_have_no_plan():
+    assert ops.plan_linear_tiled(4096, 4096, True, 129) is None
+    assert ops.linear_tiled_candidates(4096, 4096, True, 129) == []
+    assert ops.plan_linear_tiled(4096, 448, True, 32) is None          # K not a multiple of any slice width
+
+
+def test_slice_widths_and_workgroup_tiles():
+    assert [ops.tiled_slice_width(m, 8) for m in (16, 32, 64, 128)] == [1024, 1024, 512, 256]
+    assert [ops.tiled_slice_width(m, 104) for m in (16, 32, 64, 128)] == [512, 512, 256, 128]
+    assert ops.tiled_slice_width(64, 208) == 256 and ops.tiled_slice_width(64, 216) == 512
+    assert ops.tiled_slice_width(128, 216) == 256
+    assert [ops.tiles_per_workgroup(t) for t in (4, 8, 104, 108, 208, 216)] == [4, 8, 4, 8, 8, 16]
