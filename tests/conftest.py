@@ -1,4 +1,6 @@
-"""Shared pytest configuration: markers, import paths and golden-vector loading."""
+"""Shared pytest configuration: markers, import paths, golden-vector loading, the order of the
+GPU files and what a native abort leaves behind."""
+import faulthandler
 import os
 import sys
 
@@ -13,9 +15,55 @@ for p in (ROOT, PKG):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# GPU files in the order they run: operator parity against the oracle first, then the whole
+# model, tensor parallelism and the served path; the real-width configuration steps (the
+# largest allocations and the widest kernels) after them, the allocation-free entry point last.
+# With `-x` one failing file then cannot hide the parity results of the files before it.
+GPU_ORDER = ("test_ops_gpu", "test_model_gpu", "test_tp_gpu", "test_plumbing_gpu", "test_configs_gpu")
+_fault_log = None
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box only)")
+    # A native abort (HIP / HSA runtime, glibc) prints its reason to fd 2 and raises SIGABRT.
+    # pytest.ini keeps fd 2 uncaptured (--capture=sys) and pytest's own all-threads traceback
+    # dump off, so that reason stays the last thing in the log; the Python frames of every
+    # thread go to a side file instead.
+    global _fault_log
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        _fault_log = open(os.path.join(ROOT, "gpurun_out", "pytest_fault.log"), "w")
+        faulthandler.enable(file=_fault_log, all_threads=True)
+    except OSError:
+        faulthandler.enable(all_threads=False)
+
+
+def pytest_collection_modifyitems(config, items):
+    def key(item):
+        name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        if name.startswith("test_zz"):
+            return (2, 0)
+        if name in GPU_ORDER:
+            return (1, GPU_ORDER.index(name))
+        return (0, 0)
+    items.sort(key=key)                       # stable: the order inside a file is kept
+
+
+_last_file = [None]
+
+
+def pytest_runtest_logstart(nodeid, location):
+    """One line on fd 2 per GPU test file (per case for the real-width steps): a native abort
+    then names where it happened even though pytest never gets to report the test."""
+    fname = nodeid.split("::")[0]
+    if "_gpu" not in fname and "test_zz" not in fname:
+        return
+    if fname != _last_file[0] or "test_configs_gpu" in fname:
+        _last_file[0] = fname
+        try:
+            os.write(2, f"\n[gpu tests] {nodeid}\n".encode())
+        except OSError:
+            pass
 
 
 def load_npz(name):

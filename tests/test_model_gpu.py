@@ -456,18 +456,24 @@ def test_prompt_logprobs_match_the_oracle(chunk):
 
 
 def test_failed_graph_capture_falls_back_to_eager_launches(monkeypatch):
-    """If the decode step cannot be captured (e.g. a collective the runtime refuses to capture), the
-    engine keeps serving with eager launches and the same tokens."""
+    """If the decode step cannot be captured under tensor parallelism (e.g. a collective the runtime
+    refuses to capture), the engine keeps serving with eager launches and the same tokens, and
+    counts the failure; on one GPU the same failure is an error, not a silent slow path."""
     name = "llama_d64"
     prompts = make_prompts(name, len(LENGTHS), LENGTHS)
     eng_ok, _, _ = build(name, "bfloat16")
     want = engine_generate(eng_ok, prompts, 10)
     eng, _, _ = build(name, "bfloat16")
+    strict, _, _ = build(name, "bfloat16")
 
     class Refuses:
         def __init__(self, *a, **k):
             raise RuntimeError("capture refused (test)")
     monkeypatch.setattr(torch.cuda, "graph", Refuses)
+    eng.runner.allow_eager_fallback = True            # what a tensor-parallel rank is built with
     got = engine_generate(eng, prompts, 10)
-    assert eng.runner.use_graphs is False and not eng.runner.graphs
+    assert eng.runner.use_graphs is False and not eng.runner.graphs and eng.runner.capture_failures == 1
     np.testing.assert_array_equal(got, want)
+    assert strict.runner.allow_eager_fallback is False
+    with pytest.raises(RuntimeError, match="capture refused"):
+        engine_generate(strict, prompts, 10)

@@ -104,6 +104,14 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
                       f"mi355_num_requests_waiting {len(eng.sched.waiting)}",
                       f"mi355_kv_blocks_free {eng.alloc.num_free}",
                       f"mi355_kv_blocks_total {eng.alloc.num_blocks}"]
+            r = getattr(eng, "runner", None)
+            if r is not None:          # degraded modes: eager launches instead of graph replay, untimed GEMM plans
+                lines += [f"mi355_hip_graphs_enabled {int(bool(r.use_graphs))}",
+                          f"mi355_graph_capture_failures_total {r.capture_failures}",
+                          f"mi355_gemm_tune_failures_total {r.tune_failures}"]
+                for bucket, mode in sorted(r._modes.items()):
+                    for proj, tiled in mode.items():
+                        lines.append(f'mi355_gemm_form{{bucket="{bucket}",projection="{proj}"}} {int(bool(tiled))}')
         return Response("\n".join(lines) + "\n", media_type="text/plain")
 
     @app.post("/v1/completions")
@@ -319,7 +327,9 @@ def main(argv: Optional[List[str]] = None) -> int:
         eng = build_engine(args, model_config=cfg)
         if args.tensor_parallel_size > 1:
             import torch.distributed as dist
-            control = dist.new_group(backend="gloo")
+            import datetime
+            control = dist.new_group(backend="gloo", timeout=datetime.timedelta(
+                seconds=int(os.environ.get("MI355_DIST_TIMEOUT_S", "300"))))
             thread.control_group = control
         return eng
 
@@ -334,18 +344,30 @@ def main(argv: Optional[List[str]] = None) -> int:
     config = uvicorn.Config(app, host=ns.host, port=ns.port, log_level="warning", access_log=False)
     server = uvicorn.Server(config)
 
+    lost = []
+
     async def serve():
         task = asyncio.create_task(server.serve())
         while not task.done():
             await asyncio.sleep(0.5)
             if thread.failed is not None:            # fatal engine error: exit non-zero
                 server.should_exit = True
+            # a tensor-parallel worker that died leaves rank 0 blocked in its next collective with
+            # /health still answering: exit non-zero instead, so the pod is restarted as a whole
+            dead = [p.pid for p in workers if p.poll() is not None]
+            if dead and not lost:
+                lost.extend(dead)
+                log.error("tensor-parallel worker process(es) %s exited; shutting the server down", dead)
+                thread.failed = thread.failed or RuntimeError(f"tensor-parallel worker {dead} exited")
+                server.should_exit = True
         await task
 
     asyncio.run(serve())
-    thread.shutdown()
+    if not lost:
+        thread.shutdown()
     for p in workers:
-        p.terminate()
+        if p.poll() is None:
+            p.terminate()
     return 1 if thread.failed is not None else 0
 
 

@@ -38,10 +38,14 @@ def init_distributed(tp_size: int):
         device = torch.device("cuda", local)
         torch.cuda.set_device(device)
         if not torch.distributed.is_initialized():
+            # a peer that died must surface as an error on the others, not as a collective that
+            # never returns (rank 0 talks to the workers at least every 50 ms, idle or not)
+            import datetime
+            timeout = datetime.timedelta(seconds=int(os.environ.get("MI355_DIST_TIMEOUT_S", "300")))
             if backend == "nccl":
-                torch.distributed.init_process_group("nccl", device_id=device)
+                torch.distributed.init_process_group("nccl", device_id=device, timeout=timeout)
             else:
-                torch.distributed.init_process_group(backend)
+                torch.distributed.init_process_group(backend, timeout=timeout)
         return rank, world, device, torch.distributed.group.WORLD
     device = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(device)

@@ -93,6 +93,12 @@ class ModelRunner:
         self.max_model_len = int(max_model_len)
         self.max_blocks = (self.max_model_len + BLOCK_SIZE - 1) // BLOCK_SIZE
         self.use_graphs = use_graphs
+        # A decode step that cannot be captured (a collective the RCCL build refuses to capture) may
+        # run as eager launches instead -- only under tensor parallelism, where that can happen;
+        # on one GPU a failed capture or a failed timing run is an error and is raised.
+        self.allow_eager_fallback = tp_size > 1
+        self.capture_failures = 0                     # exported on /metrics and in the bench line
+        self.tune_failures = 0
         self._device_collectives = None               # decided at the first collective (see _collective)
         self.decode_splits = decode_splits
         self.weight_fp8 = bool(weight_fp8)
@@ -366,6 +372,9 @@ class ModelRunner:
                     avail[k] = best
                     mode[k] = best_us <= 1.05 * tl          # near-ties stay tiled: the choice should not flip from run to run
             except RuntimeError as exc:                     # timing replays graphs: without them, no choice is made
+                if isinstance(exc, Mi355Error) or not self.allow_eager_fallback:
+                    raise
+                self.tune_failures += 1
                 import logging
                 logging.getLogger("mi355_decode").warning(
                     "timing the GEMM forms for batch bucket %d failed (%s); using the tiled kernels", bucket, exc)
@@ -629,7 +638,11 @@ class ModelRunner:
                 self.capture(bucket)
             except RuntimeError as exc:
                 # e.g. a collective that cannot be captured on this RCCL build: every rank takes the
-                # same exception at the same step, so all fall back to eager launches together
+                # same exception at the same step, so all fall back to eager launches together.
+                # A kernel or argument error (Mi355Error) is never a capture problem.
+                if isinstance(exc, Mi355Error) or not self.allow_eager_fallback:
+                    raise
+                self.capture_failures += 1
                 import logging
                 logging.getLogger("mi355_decode").warning(
                     "HIP-graph capture of the decode step failed (%s); continuing with eager launches", exc)

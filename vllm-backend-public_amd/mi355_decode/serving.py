@@ -7,8 +7,9 @@ through a thread-safe inbox; every generated token is handed back to the
 request's asyncio queue with ``loop.call_soon_threadsafe``.
 
 Under tensor parallelism rank 0 owns the HTTP socket; each loop iteration it
-broadcasts the requests/aborts it has collected (gloo, CPU objects) and then all
-ranks advance their identical engines by one step.
+broadcasts how many bytes of requests/aborts it has collected (gloo, one 8-byte
+tensor) and the pickled messages only when there are any, then all ranks advance
+their identical engines by one step.
 """
 from __future__ import annotations
 
@@ -83,13 +84,25 @@ class EngineThread:
         return msgs
 
     def _exchange(self, msgs: list) -> list:
-        """Rank 0 -> all ranks: this iteration's control messages."""
+        """Rank 0 -> all ranks: this iteration's control messages.  Every iteration broadcasts one
+        8-byte length; a payload (the pickled messages) follows only when rank 0 collected any, so
+        a decode step with an empty inbox costs one small gloo broadcast and no serialisation."""
         if self.control_group is None:
             return msgs
+        import pickle
+
+        import torch
         import torch.distributed as dist
-        box = [msgs if self.rank == 0 else None]
-        dist.broadcast_object_list(box, src=0, group=self.control_group)
-        return box[0]
+        payload = pickle.dumps(msgs) if self.rank == 0 and msgs else b""
+        n = torch.tensor([len(payload)], dtype=torch.int64)
+        dist.broadcast(n, src=0, group=self.control_group)
+        size = int(n.item())
+        if size == 0:
+            return []
+        buf = (torch.frombuffer(bytearray(payload), dtype=torch.uint8) if self.rank == 0
+               else torch.empty(size, dtype=torch.uint8))
+        dist.broadcast(buf, src=0, group=self.control_group)
+        return msgs if self.rank == 0 else pickle.loads(buf.numpy().tobytes())
 
     def _run(self):
         try:
