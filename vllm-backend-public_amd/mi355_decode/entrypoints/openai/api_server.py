@@ -105,11 +105,11 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
                       f"mi355_kv_blocks_free {eng.alloc.num_free}",
                       f"mi355_kv_blocks_total {eng.alloc.num_blocks}"]
             r = getattr(eng, "runner", None)
-            if r is not None:          # degraded modes: eager launches instead of graph replay, untimed GEMM plans
+            if r is not None and hasattr(r, "capture_failures"):   # degraded modes: eager launches instead of graph replay, untimed GEMM plans
                 lines += [f"mi355_hip_graphs_enabled {int(bool(r.use_graphs))}",
                           f"mi355_graph_capture_failures_total {r.capture_failures}",
                           f"mi355_gemm_tune_failures_total {r.tune_failures}"]
-                for bucket, mode in sorted(r._modes.items()):
+                for bucket, mode in sorted(getattr(r, "_modes", {}).items()):
                     for proj, tiled in mode.items():
                         lines.append(f'mi355_gemm_form{{bucket="{bucket}",projection="{proj}"}} {int(bool(tiled))}')
         return Response("\n".join(lines) + "\n", media_type="text/plain")
