@@ -149,8 +149,12 @@ def test_rank_decode_step_matches_oracle(case):
               f"({err.max() / scale:.2e} rel), mean {err.mean() / scale:.2e} rel; {int(same.sum())}/{len(tk)} "
               f"greedy tokens equal, worst margin of the others {gaps.max() if len(gaps) else 0:.2e}")
         assert err.max() <= MAX_TOL * scale and err.mean() <= MEAN_TOL * scale
-        assert (gaps >= 0).all() and (gaps <= 2 * MAX_TOL * scale).all()
-        assert same.mean() >= 0.9
+        # the sampled token is exactly the lowest-index argmax of the step's own logits ...
+        np.testing.assert_array_equal(tk - (rank * want.shape[1] if shard_mlp else 0), R.argmax_lowest(lg))
+        # ... so it can leave the oracle's only where the oracle's margin is inside twice the logit error
+        # (random weights give flat logits: near-ties are common, 2 of 16 rows were seen)
+        assert (gaps >= 0).all() and (gaps <= 2 * err.max() + 1e-6).all()
+        assert same.mean() >= 0.75
     err = np.abs(lt - ll)
     assert err.max() <= MAX_TOL * scale and err.mean() <= MEAN_TOL * scale
-    assert (tt == tl).mean() >= 0.9
+    assert (tt == tl).mean() >= 0.75
