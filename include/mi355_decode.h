@@ -141,6 +141,31 @@ int32_t mi355_paged_attn_decode(void* out, const void* q, int64_t q_stride,
                                 void* stream);
 
 /*
+ * mi355_paged_attn_decode for callers that cannot allocate device memory (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc):
+ * the same kernels, with the split-KV partials in a device array built into the
+ * library (MI355_PAGED_ATTN_DECODE_STATIC_MAX_BYTES per GPU the library runs on,
+ * held until the process ends) instead of a caller workspace.  No counterpart in
+ * the reference.  Calls no hipMalloc, hipFree or other allocating routine; the first
+ * call on a device looks the array's address up (hipGetSymbolAddress) -- make it
+ * outside stream capture.  MI355_ERR_UNSUPPORTED when
+ * mi355_paged_attn_decode_workspace(num_seqs, num_heads, head_dim, num_splits)
+ * exceeds the array.  All calls on one GPU share the array: calls that overlap on
+ * one GPU (different streams) race; calls on one stream are ordered.  Nothing in
+ * the array has to be cleared between calls (a launch reads only what it wrote).
+ */
+#define MI355_PAGED_ATTN_DECODE_STATIC_MAX_BYTES (16 * 1024 * 1024)
+int32_t mi355_paged_attn_decode_static(void* out, const void* q, int64_t q_stride,
+                                       const void* k_cache, const void* v_cache,
+                                       int32_t num_blocks, const int32_t* block_tables,
+                                       int32_t max_blocks_per_seq,
+                                       const int32_t* context_lens, int32_t num_seqs,
+                                       int32_t num_heads, int32_t num_kv_heads,
+                                       int32_t head_dim, float scale,
+                                       int32_t num_splits, int32_t dtype,
+                                       void* stream);
+
+/*
  * Decode attention with the rotary embedding and the KV store of the new token
  * fused in: the projection of the step (packed q|k|v rows) is rotated and stored
  * exactly as mi355_rope_kv_write would, then attended to exactly as

@@ -611,6 +611,62 @@ extern "C" int32_t mi355_paged_attn_decode(void* out, const void* q, int64_t q_s
                              workspace_bytes, dtype, stream, 0, mi355::RopeArgs{});
 }
 
+// ---- the entry point that allocates nothing.  The split-KV partials (fp32 accumulators and
+// softmax statistics per (sequence, head, split), the only device memory the decode kernels use
+// beyond their inputs and outputs) live in a file-scope device array instead of a caller
+// workspace.  In host code the array's NAME is only a handle: the address the kernels get is
+// looked up once per device with hipGetSymbolAddress (every GPU holds its own copy of the array
+// at its own address) and kept.
+namespace mi355 {
+
+constexpr int64_t kStaticScratchBytes = MI355_PAGED_ATTN_DECODE_STATIC_MAX_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+constexpr int kMaxDevices = 64;
+static void* g_scratch_ptr[kMaxDevices];          // per device, written once under the lock
+
+static int32_t static_scratch(const char* name, void** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  MI355_REQUIRE(e == hipSuccess && dev >= 0 && dev < kMaxDevices, MI355_ERR_INVALID, "%s: no current device (%s)",
+                name, hipGetErrorString(e));
+  void* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (p == nullptr) {
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    MI355_REQUIRE(e == hipSuccess && p != nullptr, MI355_ERR_LAUNCH,
+                  "%s: hipGetSymbolAddress of the scratch array failed on device %d: %s", name, dev,
+                  hipGetErrorString(e));
+    __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE);   // the same value from every thread
+  }
+  *out = p;
+  return MI355_OK;
+}
+
+}  // namespace mi355
+
+extern "C" int32_t mi355_paged_attn_decode_static(void* out, const void* q, int64_t q_stride, const void* k_cache,
+                                                  const void* v_cache, int32_t num_blocks,
+                                                  const int32_t* block_tables, int32_t max_blocks_per_seq,
+                                                  const int32_t* context_lens, int32_t num_seqs, int32_t num_heads,
+                                                  int32_t num_kv_heads, int32_t head_dim, float scale,
+                                                  int32_t num_splits, int32_t dtype, void* stream) {
+  const char* name = "mi355_paged_attn_decode_static";
+  const int64_t need = mi355_paged_attn_decode_workspace(num_seqs, num_heads, head_dim, num_splits);
+  MI355_REQUIRE(need <= mi355::kStaticScratchBytes, MI355_ERR_UNSUPPORTED,
+                "%s: %d sequences x %d heads x %d splits need %lld bytes of partials, the built-in scratch holds %lld "
+                "(use mi355_paged_attn_decode with a workspace)", name, num_seqs, num_heads, num_splits,
+                (long long)need, (long long)mi355::kStaticScratchBytes);
+  void* ws = nullptr;
+  const int32_t rc = mi355::static_scratch(name, &ws);
+  if (rc != MI355_OK) return rc;
+  // every partial a launch reads was written by that launch (each workgroup stores all of its
+  // entries, empty splits included): nothing has to start at zero
+  return mi355::decode_entry(name, out, q, q_stride, const_cast<void*>(k_cache), const_cast<void*>(v_cache),
+                             num_blocks, block_tables, max_blocks_per_seq, context_lens, num_seqs, num_heads,
+                             num_kv_heads, head_dim, scale, num_splits, ws, mi355::kStaticScratchBytes, dtype, stream, 0,
+                             mi355::RopeArgs{});
+}
+
 extern "C" int32_t mi355_paged_attn_decode_fused(void* out, const void* qkv, int64_t qkv_stride,
                                                  const float* partial, int32_t num_slabs, int64_t slab_stride,
                                                  const void* bias, const void* cos_sin,

@@ -185,6 +185,31 @@ def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
     return out
 
 
+STATIC_SCRATCH_BYTES = 16 * 1024 * 1024       # MI355_PAGED_ATTN_DECODE_STATIC_MAX_BYTES
+
+
+def paged_attn_decode_static(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                             block_tables: torch.Tensor, context_lens: torch.Tensor, num_heads: int,
+                             num_kv_heads: int, head_dim: int, scale: float, num_splits: int, out: torch.Tensor):
+    """paged_attn_decode through the entry point that allocates nothing: the split-KV partials live in
+    the library's built-in device array, `out` must be given (this wrapper creates no tensor either)."""
+    dt = _dt16(q, "q")
+    B = q.shape[0]
+    nb = _check_cache(q, k_cache, v_cache, block_tables, num_kv_heads, head_dim)
+    _dev(context_lens, "context_lens")
+    if context_lens.dtype != torch.int32 or context_lens.numel() != B or not context_lens.is_contiguous():
+        raise ValueError("context_lens must be contiguous int32 [num_seqs]")
+    if block_tables.shape[0] != B:
+        raise ValueError("block_tables rows must equal num_seqs")
+    if not out.is_contiguous() or out.numel() != B * num_heads * head_dim or out.dtype != q.dtype:
+        raise ValueError("out must be contiguous [num_seqs, num_heads*head_dim]")
+    check(lib.mi355_paged_attn_decode_static(out.data_ptr(), q.data_ptr(), _rows(q, "q"), k_cache.data_ptr(),
+                                             v_cache.data_ptr(), nb, block_tables.data_ptr(), block_tables.shape[1],
+                                             context_lens.data_ptr(), B, num_heads, num_kv_heads, head_dim,
+                                             float(scale), num_splits, dt, _stream()))
+    return out
+
+
 def paged_attn_decode_fused(qkv: torch.Tensor | None, cos_sin: torch.Tensor, slot_mapping: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                             block_tables: torch.Tensor, context_lens: torch.Tensor, num_heads: int,
                             num_kv_heads: int, head_dim: int, scale: float, num_splits: int = 1,
