@@ -86,6 +86,19 @@ int32_t mi355_fused_add_rms_norm(void* out, const void* x, void* residual,
                                  float eps, int32_t dtype, void* stream);
 
 /*
+ * First kernel of a decode step: residual[t, :] = embed[token_ids[t], :] and
+ * out[t, :] = rms_norm(residual[t, :]) in one launch (the embedding lookup of
+ * the served model + the first layer's input norm).  embed [vocab, hidden], row
+ * stride embed_stride; an id outside [0, vocab) reads row 0.
+ */
+int32_t mi355_embed_rms_norm(void* out, void* residual, const void* embed,
+                             const int64_t* token_ids, int64_t vocab,
+                             const void* weight, int64_t num_tokens, int32_t hidden,
+                             int64_t embed_stride, int64_t out_stride,
+                             int64_t residual_stride, float eps, int32_t dtype,
+                             void* stream);
+
+/*
  * Rotary embedding (NeoX / rotate-half pairing (i, i + head_dim/2)) applied in
  * place to the q and k parts of the packed QKV projection output, fused with the
  * paged KV-cache store of k (rotated) and v.
@@ -236,6 +249,19 @@ int32_t mi355_silu_and_mul(void* out, const void* x, int64_t x_stride,
 int32_t mi355_argmax(int64_t* out_ids, const void* logits,
                      int64_t logits_stride, int32_t num_rows, int32_t vocab,
                      int32_t logits_dtype, void* stream);
+
+/*
+ * mi355_argmax for few rows (a decode batch): every row is cut into column ranges
+ * handled by separate workgroups whose best keys are merged with a 64-bit atomic
+ * max into keys[row], then turned into token ids (same ids as mi355_argmax, on
+ * every launch).  `keys` int64 [num_rows]: zero before the first call, left zero
+ * by every call.  out_ids2 (may be NULL) receives the same ids a second time (the
+ * next step's input tokens, so that they never leave the GPU).
+ */
+int32_t mi355_argmax_chunked(int64_t* out_ids, int64_t* out_ids2, int64_t* keys,
+                             const void* logits, int64_t logits_stride,
+                             int32_t num_rows, int32_t vocab, int32_t logits_dtype,
+                             void* stream);
 
 /*
  * Greedy sampling over a vocabulary that is split across tensor-parallel ranks

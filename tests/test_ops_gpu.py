@@ -384,6 +384,57 @@ def test_argmax_over_vocabulary_shards(ops, ops_golden, ldt, B, V, shards):
     np.testing.assert_array_equal(ids, ops.argmax(full).cpu().numpy())
 
 
+@pytest.mark.parametrize("ldt", ["bfloat16", "float16", "float32"])
+@pytest.mark.parametrize("B,V", [(1, 16), (3, 1000), (32, 128256), (7, 50272), (128, 152064), (2, 8200)])
+def test_argmax_chunked(ops, ldt, B, V):
+    """The many-workgroup argmax of a decode batch: the oracle's ids (lowest index on ties, also
+    across column ranges; NaN on top; signed zeros equal), both destinations written, the key
+    buffer left zero, same ids on a second launch."""
+    rng = rng_for("argmax-chunked", ldt, B, V)
+    lg = R.round_to((rng.standard_normal((B, V)) * 4).astype(np.float32), ldt)
+    hi = 64.0
+    if V > 16:
+        lg[0, [V // 3, V - 3]] = hi                      # a tie across column ranges -> lowest index
+        lg[B - 1, :] = 0.0
+        lg[B - 1, V // 2] = -0.0
+        if B > 2:
+            lg[1, V - 5] = np.nan
+            lg[1, 3] = hi
+    tdt = {"float32": torch.float32, **DT}[ldt]
+    stride = (V + 7) // 8 * 8
+    buf = torch.full((B, stride), float("-inf"), dtype=tdt, device="cuda")
+    buf[:, :V] = torch.from_numpy(lg).to(tdt).cuda()
+    keys = torch.zeros(B + 3, dtype=torch.int64, device="cuda")
+    out = torch.full((B,), -7, dtype=torch.int64, device="cuda")
+    out2 = torch.full((B,), -7, dtype=torch.int64, device="cuda")
+    ref = R.argmax_lowest(lg)
+    for _ in range(2):
+        ops.argmax_chunked(buf[:, :V], keys, out, out2)
+        np.testing.assert_array_equal(out.cpu().numpy(), ref)
+        np.testing.assert_array_equal(out2.cpu().numpy(), ref)
+        assert int(keys.abs().sum().item()) == 0
+    np.testing.assert_array_equal(ops.argmax(buf[:, :V]).cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("T,H,V", [(1, 256, 50), (32, 4096, 1000), (5, 8192, 77), (3, 16384, 9), (130, 448, 300)])
+def test_embed_rms_norm(ops, dtype, T, H, V):
+    """Embedding gather + first input norm in one launch: the residual rows are the embedding rows
+    bit for bit, the normed rows meet the RMSNorm bar; ids outside the table read row 0."""
+    rng = rng_for("embed-norm", dtype, T, H)
+    emb = grid(rng, (V, H), dtype, 2.0)
+    w = R.round_to(1 + 0.1 * rng.standard_normal(H), dtype)
+    ids = rng.integers(0, V, T).astype(np.int64)
+    if T > 2:
+        ids[1], ids[2] = -4, V + 9
+    safe = np.where((ids < 0) | (ids >= V), 0, ids)
+    resid = torch.full((T, H), float("nan"), dtype=DT[dtype], device="cuda")
+    x = torch.full((T, H), float("nan"), dtype=DT[dtype], device="cuda")
+    ops.embed_rms_norm(dev(emb, dtype), torch.from_numpy(ids).cuda(), dev(w, dtype), 1e-5, resid, x)
+    np.testing.assert_array_equal(host(resid), emb[safe])
+    assert_ulp_close(host(x), R.rms_norm(emb[safe], w, 1e-5, dtype), dtype, 0.005)
+
+
 def test_argmax_golden_and_nan(ops, ops_golden):
     lg = ops_golden["argmax_logits"]
     out = ops.argmax(torch.from_numpy(lg).cuda())

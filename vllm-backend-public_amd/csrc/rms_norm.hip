@@ -211,6 +211,50 @@ __global__ __launch_bounds__(kThreads) void rms_norm_slabs_kernel(
   }
 }
 
+// First kernel of a decode step: the embedding gather and the first layer's RMSNorm in one
+// launch.  Row b of the residual stream is embedding row ids[b] (copied as is), x is its norm.
+// An id outside [0, vocab) reads row 0 (the engine validates ids on admission; a padded row of a
+// batch bucket may hold anything).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void embed_rms_norm_kernel(
+    uint16_t* __restrict__ out, uint16_t* __restrict__ residual, const uint16_t* __restrict__ embed,
+    const int64_t* __restrict__ ids, int64_t vocab, const uint16_t* __restrict__ weight, int hidden,
+    int64_t embed_stride, int64_t out_stride, int64_t res_stride, float eps) {
+  const int64_t row = blockIdx.x;
+  int64_t id = ids[row];
+  id = (id < 0 || id >= vocab) ? 0 : id;
+  const int nvec = hidden >> 3;
+  const uint4* er = reinterpret_cast<const uint4*>(embed + id * embed_stride);
+  uint4* rr = reinterpret_cast<uint4*>(residual + row * res_stride);
+  uint4* orow = reinterpret_cast<uint4*>(out + row * out_stride);
+  const uint4* wv = reinterpret_cast<const uint4*>(weight);
+  float ss = 0.f;
+  for (int v = threadIdx.x; v < nvec; v += kThreads) {
+    const uint4 raw = er[v];
+    rr[v] = raw;
+    float f[8];
+    unpack8<T>(raw, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+  }
+  __shared__ float part[kThreads / 64];
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  float total = 0.f;
+#pragma unroll
+  for (int i = 0; i < kThreads / 64; ++i) total += part[i];
+  const float inv = 1.0f / sqrtf(total / static_cast<float>(hidden) + eps);
+  for (int v = threadIdx.x; v < nvec; v += kThreads) {
+    float f[8], w[8], y[8];
+    unpack8<T>(er[v], f);                 // an L2 hit: this thread just read it
+    unpack8<T>(wv[v], w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = round_f<T>(f[j] * inv) * w[j];
+    orow[v] = pack8<T>(y);
+  }
+}
+
 template <bool ADD, bool PART = false>
 static int32_t launch(void* out, const void* x, void* residual, const void* weight,
                       int64_t num_tokens, int32_t hidden, int64_t x_stride, int64_t out_stride,
@@ -314,4 +358,36 @@ extern "C" int32_t mi355_fused_add_rms_norm_partial(void* out, const float* part
   // `partial` stands in for x in the shared argument checks (16-byte alignment, non-null)
   return mi355::launch<true, true>(out, partial, residual, weight, num_tokens, hidden, hidden, out_stride,
                                    residual_stride, eps, dtype, stream, partial, num_slabs, slab_stride, bias);
+}
+
+extern "C" int32_t mi355_embed_rms_norm(void* out, void* residual, const void* embed, const int64_t* token_ids,
+                                        int64_t vocab, const void* weight, int64_t num_tokens, int32_t hidden,
+                                        int64_t embed_stride, int64_t out_stride, int64_t residual_stride, float eps,
+                                        int32_t dtype, void* stream) {
+  using namespace mi355;
+  const char* name = "mi355_embed_rms_norm";
+  MI355_REQUIRE(out && residual && embed && token_ids && weight, MI355_ERR_INVALID, "%s: null pointer", name);
+  MI355_REQUIRE(num_tokens >= 0 && num_tokens <= 0x7FFFFFFF && vocab > 0, MI355_ERR_INVALID,
+                "%s: num_tokens %lld / vocab %lld out of range", name, (long long)num_tokens, (long long)vocab);
+  MI355_REQUIRE(hidden > 0 && hidden % 8 == 0, MI355_ERR_UNSUPPORTED, "%s: hidden %d must be a positive multiple of 8",
+                name, hidden);
+  MI355_REQUIRE(embed_stride >= hidden && out_stride >= hidden && residual_stride >= hidden && embed_stride % 8 == 0 &&
+                    out_stride % 8 == 0 && residual_stride % 8 == 0,
+                MI355_ERR_INVALID, "%s: row strides must be >= hidden and multiples of 8", name);
+  MI355_REQUIRE(aligned16(out) && aligned16(residual) && aligned16(embed) && aligned16(weight), MI355_ERR_INVALID,
+                "%s: pointers must be 16-byte aligned", name);
+  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED,
+                "%s: dtype %d not supported (bf16/fp16 only)", name, dtype);
+  if (num_tokens == 0) return MI355_OK;
+  dim3 grid(static_cast<unsigned>(num_tokens)), block(kThreads);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == MI355_BF16)
+    hipLaunchKernelGGL((embed_rms_norm_kernel<BF16>), grid, block, 0, s, static_cast<uint16_t*>(out),
+                       static_cast<uint16_t*>(residual), static_cast<const uint16_t*>(embed), token_ids, vocab,
+                       static_cast<const uint16_t*>(weight), hidden, embed_stride, out_stride, residual_stride, eps);
+  else
+    hipLaunchKernelGGL((embed_rms_norm_kernel<F16>), grid, block, 0, s, static_cast<uint16_t*>(out),
+                       static_cast<uint16_t*>(residual), static_cast<const uint16_t*>(embed), token_ids, vocab,
+                       static_cast<const uint16_t*>(weight), hidden, embed_stride, out_stride, residual_stride, eps);
+  return check_launch(name);
 }

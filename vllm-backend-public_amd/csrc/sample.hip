@@ -85,6 +85,68 @@ __global__ __launch_bounds__(kArgmaxThreads) void argmax_kernel(int64_t* __restr
   }
 }
 
+// Chunked form for few rows: one 1024-thread workgroup per row draws its 8 MB alone (14 us for
+// 32 x 128256); here a row is cut into `chunks` column ranges, every (row, chunk) workgroup
+// max-reduces its range to one key and merges it into keys[row] with a 64-bit atomic max (order
+// does not matter for a max: same result on every launch), and a second, tiny kernel turns the
+// keys into token ids and clears them for the next launch.
+template <int LDT>
+__global__ __launch_bounds__(256) void argmax_chunk_kernel(unsigned long long* __restrict__ keys,
+                                                            const void* __restrict__ logits, int64_t stride,
+                                                            int vocab, int chunk_vecs) {
+  constexpr int PER = LDT == MI355_F32 ? 4 : 8;     // elements per 16-byte vector
+  const int row = blockIdx.x;
+  const int nvec = vocab / PER;
+  const int v0 = blockIdx.y * chunk_vecs, v1 = min(nvec, v0 + chunk_vecs);
+  unsigned long long best = 0ull;
+  if (LDT == MI355_F32) {
+    const float* p = static_cast<const float*>(logits) + row * stride;
+    for (int v = v0 + threadIdx.x; v < v1; v += 256) {
+      const float4 f = *reinterpret_cast<const float4*>(p + 4 * v);
+      best = umax64(best, argmax_key(f.x, 4 * v));
+      best = umax64(best, argmax_key(f.y, 4 * v + 1));
+      best = umax64(best, argmax_key(f.z, 4 * v + 2));
+      best = umax64(best, argmax_key(f.w, 4 * v + 3));
+    }
+    if (blockIdx.y == gridDim.y - 1)
+      for (int i = nvec * PER + threadIdx.x; i < vocab; i += 256) best = umax64(best, argmax_key(p[i], i));
+  } else {
+    const uint16_t* p = static_cast<const uint16_t*>(logits) + row * stride;
+    for (int v = v0 + threadIdx.x; v < v1; v += 256) {
+      float f[8];
+      const uint4 raw = *reinterpret_cast<const uint4*>(p + 8 * v);
+      if (LDT == MI355_BF16) unpack8<BF16>(raw, f); else unpack8<F16>(raw, f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) best = umax64(best, argmax_key(f[j], 8 * v + j));
+    }
+    if (blockIdx.y == gridDim.y - 1)
+      for (int i = nvec * PER + threadIdx.x; i < vocab; i += 256) {
+        const float f = (LDT == MI355_BF16) ? BF16::to_f(p[i]) : F16::to_f(p[i]);
+        best = umax64(best, argmax_key(f, i));
+      }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) best = umax64(best, __shfl_xor(best, off, 64));
+  __shared__ unsigned long long part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    best = umax64(umax64(part[0], part[1]), umax64(part[2], part[3]));
+    if (best != 0ull) atomicMax(&keys[row], best);   // 0 = an empty column range (every real key is > 0)
+  }
+}
+
+__global__ void argmax_finish_kernel(int64_t* __restrict__ out, int64_t* __restrict__ out2,
+                                     unsigned long long* __restrict__ keys, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long b = keys[i];
+  keys[i] = 0ull;                                     // re-armed for the next launch
+  const int64_t idx = static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(b & 0xFFFFFFFFull));
+  out[i] = idx;
+  if (out2 != nullptr) out2[i] = idx;
+}
+
 __global__ void argmax_key_to_index_kernel(int64_t* __restrict__ out, const int64_t* __restrict__ keys, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(static_cast<unsigned long long>(keys[i]) & 0xFFFFFFFFull));
@@ -350,6 +412,42 @@ extern "C" int32_t mi355_argmax(int64_t* out_ids, const void* logits, int64_t lo
                                 int32_t num_rows, int32_t vocab, int32_t logits_dtype, void* stream) {
   return mi355::argmax_entry("mi355_argmax", out_ids, logits, logits_stride, num_rows, vocab, logits_dtype, false, 0,
                              stream);
+}
+
+extern "C" int32_t mi355_argmax_chunked(int64_t* out_ids, int64_t* out_ids2, int64_t* keys, const void* logits,
+                                        int64_t logits_stride, int32_t num_rows, int32_t vocab,
+                                        int32_t logits_dtype, void* stream) {
+  using namespace mi355;
+  const char* name = "mi355_argmax_chunked";
+  MI355_REQUIRE(out_ids && keys && logits, MI355_ERR_INVALID, "%s: null pointer", name);
+  MI355_REQUIRE(num_rows >= 0 && vocab > 0, MI355_ERR_INVALID, "%s: num_rows/vocab out of range", name);
+  MI355_REQUIRE(logits_dtype == MI355_BF16 || logits_dtype == MI355_F16 || logits_dtype == MI355_F32,
+                MI355_ERR_UNSUPPORTED, "%s: logits dtype %d not supported", name, logits_dtype);
+  const int per16 = logits_dtype == MI355_F32 ? 4 : 8;
+  MI355_REQUIRE(logits_stride >= vocab && logits_stride % per16 == 0 && aligned16(logits) &&
+                    (reinterpret_cast<uintptr_t>(keys) & 7u) == 0,
+                MI355_ERR_INVALID, "%s: logits rows must be 16-byte aligned (stride %lld), keys 8-byte aligned", name,
+                (long long)logits_stride);
+  if (num_rows == 0) return MI355_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // enough workgroups to draw from every HBM channel (>= ~512), each with at least 2 vectors per thread
+  const int nvec = vocab / per16;
+  int chunks = (512 + num_rows - 1) / num_rows;
+  chunks = chunks < 1 ? 1 : chunks > 64 ? 64 : chunks;
+  while (chunks > 1 && (nvec + chunks - 1) / chunks < 512) --chunks;
+  const int chunk_vecs = (nvec + chunks - 1) / chunks;
+  dim3 grid(num_rows, chunks), block(256);
+  auto* kp = reinterpret_cast<unsigned long long*>(keys);
+  if (logits_dtype == MI355_F32)
+    hipLaunchKernelGGL((argmax_chunk_kernel<MI355_F32>), grid, block, 0, s, kp, logits, logits_stride, vocab, chunk_vecs);
+  else if (logits_dtype == MI355_BF16)
+    hipLaunchKernelGGL((argmax_chunk_kernel<MI355_BF16>), grid, block, 0, s, kp, logits, logits_stride, vocab, chunk_vecs);
+  else
+    hipLaunchKernelGGL((argmax_chunk_kernel<MI355_F16>), grid, block, 0, s, kp, logits, logits_stride, vocab, chunk_vecs);
+  int32_t rc = check_launch(name);
+  if (rc != MI355_OK) return rc;
+  hipLaunchKernelGGL(argmax_finish_kernel, dim3((num_rows + 255) / 256), dim3(256), 0, s, out_ids, out_ids2, kp, num_rows);
+  return check_launch(name);
 }
 
 extern "C" int32_t mi355_argmax_shard_key(int64_t* out_keys, const void* logits, int64_t logits_stride,

@@ -119,8 +119,10 @@ class ModelRunner:
         # engine refreshes them with two host-to-device copies per step:
         #   in64 = ids | positions | slots            (3 * B int64)
         #   in32 = context_lens | block_tables        (B + B * max_blocks int32)
-        self.in64 = torch.zeros(3 * B, **i64)
-        self.in32 = torch.zeros(B + B * self.max_blocks, **i32)
+        # one allocation (int32 words): the 64-bit part first, so that a step's inputs are ONE copy
+        self.inall = torch.zeros(6 * B + B + B * self.max_blocks, **i32)
+        self.in64 = self.inall[:6 * B].view(torch.int64)
+        self.in32 = self.inall[6 * B:]
         self.ids, self.positions, self.slots = self.in64[:B], self.in64[B:2 * B], self.in64[2 * B:]
         self.slots.fill_(-1)
         self.ctx = self.in32[:B]
@@ -136,7 +138,10 @@ class ModelRunner:
         self.dn = torch.zeros(B, self.H, **f)
         self.logits = torch.zeros(B, self.Vl, **f)          # this rank's slice of the vocabulary
         self.next_ids = torch.zeros(B, **i64)
-        self.keys = torch.zeros(B, **i64)
+        self.keys = torch.zeros(B, **i64)             # argmax merge keys: zero between launches
+        # True while self.ids already holds the tokens the last decode step sampled (its argmax wrote
+        # them there too): a step launched ahead of the host then needs no copy of its input tokens
+        self._ids_synced = False
         self._max_splits = 16
         self.attn_ws = torch.empty(max(ops.decode_workspace_bytes(B, self.nh, self.d, self._max_splits), 16),
                                    dtype=torch.uint8, device=dev)
@@ -147,9 +152,9 @@ class ModelRunner:
             self._fake_quantize_row_major()
         # pinned host staging for the packed inputs and the sampled tokens: two sets, so
         # that the host can stage step n+1 while step n is still running
-        self.h64s = [torch.zeros(3 * B, dtype=torch.int64).pin_memory() for _ in range(self.NUM_STAGES)]
-        self.h32s = [torch.zeros(B + B * self.max_blocks, dtype=torch.int32).pin_memory()
-                     for _ in range(self.NUM_STAGES)]
+        self.h_alls = [torch.zeros(self.inall.numel(), dtype=torch.int32).pin_memory() for _ in range(self.NUM_STAGES)]
+        self.h64s = [h[:6 * B].view(torch.int64) for h in self.h_alls]
+        self.h32s = [h[6 * B:] for h in self.h_alls]
         self.h_nexts = [torch.zeros(B, dtype=torch.int64).pin_memory() for _ in range(self.NUM_STAGES)]
         self.done = [torch.cuda.Event() for _ in range(self.NUM_STAGES)]
         # log-probabilities of a step (only when a request asked for them): chosen token, top-k ids / values
@@ -432,9 +437,7 @@ class ModelRunner:
                 ops.fused_add_rms_norm(dn, resid, weight, self.eps, out=x)
 
         for i, (lw, tw) in enumerate(zip(self.w.layers, tiled)):
-            if i == 0:
-                ops.rms_norm(resid, lw.input_norm, self.eps, out=x)
-            else:
+            if i > 0:           # layer 0's input norm ran with the embedding gather
                 add_mlp_and_norm(lw.input_norm)
             if mode["qkv"]:
                 self._linear_tiled(x, tw["qkv"], self.qw, partial=self.part_qkv, tiles_per_wg=tq, k_groups=gq,
@@ -481,19 +484,26 @@ class ModelRunner:
         else:
             torch.mm(x, self.w.lm_head.t(), out=out)
 
-    def greedy(self, logits: torch.Tensor, out: torch.Tensor) -> None:
-        """Greedy token of every row.  With the vocabulary split over the ranks each rank reduces its
+    def greedy(self, logits: torch.Tensor, out: torch.Tensor, ids_out: Optional[torch.Tensor] = None) -> None:
+        """Greedy token of every row (`ids_out`: a second destination, the next step's input tokens).  With the vocabulary split over the ranks each rank reduces its
         slice to one 64-bit (logit, global index) key per row and the keys are max-reduced: 8 bytes
         per row cross the links instead of the logits, and the result equals the argmax over the
         whole vocabulary (lowest index on ties) on every rank."""
         if not self.vocab_sharded:
-            ops.argmax(logits, out=out)
+            if logits.shape[0] <= self.keys.numel():
+                ops.argmax_chunked(logits, self.keys, out, ids_out)
+            else:
+                ops.argmax(logits, out=out)
+                if ids_out is not None:
+                    ids_out.copy_(out)
             return
         keys = self.keys[: logits.shape[0]] if logits.shape[0] <= self.keys.numel() else \
             torch.empty(logits.shape[0], dtype=torch.int64, device=self.device)
         ops.argmax_shard_key(logits, self.vocab_offset, out=keys)
         self._allreduce_max(keys)
         ops.argmax_key_to_index(keys, out=out)
+        if ids_out is not None:
+            ids_out.copy_(out)
 
     def _allreduce_max(self, t: torch.Tensor) -> None:
         if self.tp_size > 1:
@@ -582,10 +592,13 @@ class ModelRunner:
     # ------------------------------------------------------------------ #
     def _decode_body(self, b: int) -> None:
         ids, pos, slots, ctx, bt = self.ids[:b], self.positions[:b], self.slots[:b], self.ctx[:b], self.block_tables[:b]
-        torch.index_select(self.w.embed, 0, ids, out=self.resid[:b])
+        if self.L > 0:          # embedding gather + the first layer's input norm in one launch
+            ops.embed_rms_norm(self.w.embed, ids, self.w.layers[0].input_norm, self.eps, self.resid[:b], self.x[:b])
+        else:
+            torch.index_select(self.w.embed, 0, ids, out=self.resid[:b])
         self._decode_layers(b, slots, bt, ctx, self._splits_for(b))
         self.lm_head_logits(self.x[:b], self.logits[:b])
-        self.greedy(self.logits[:b], self.next_ids[:b])
+        self.greedy(self.logits[:b], self.next_ids[:b], ids_out=ids)
 
     def bucket_for(self, batch: int) -> int:
         for s in self.buckets:
@@ -694,16 +707,17 @@ class ModelRunner:
         computes the log-probability of every row's token and of its `logprobs` most likely ones."""
         B = self.max_num_seqs
         if ids_from_device:
-            self.in64[B:].copy_(self.h64s[stage][B:], non_blocking=True)
-            self.ids[:batch].copy_(self.next_ids[:batch], non_blocking=True)
+            self.inall[2 * B:].copy_(self.h_alls[stage][2 * B:], non_blocking=True)   # everything but the token ids
+            if not self._ids_synced:
+                self.ids[:batch].copy_(self.next_ids[:batch], non_blocking=True)
         else:
-            self.in64.copy_(self.h64s[stage], non_blocking=True)
-        self.in32.copy_(self.h32s[stage], non_blocking=True)
+            self.inall.copy_(self.h_alls[stage], non_blocking=True)
         nxt = self.decode(batch)
         if sampling is not None or logprobs >= 0:
             logits = self.full_logits(self.logits[:batch])
         if sampling is not None:
             self._sample(logits, sampling, nxt)
+        self._ids_synced = sampling is None          # re-drawn rows are in next_ids only
         self.h_nexts[stage][:batch].copy_(nxt, non_blocking=True)
         if logprobs >= 0:
             self.h_lp[stage][:batch, : 1 + 2 * logprobs].copy_(self._logprobs(logits, nxt, logprobs),

@@ -312,6 +312,41 @@ def argmax(logits: torch.Tensor, out: torch.Tensor | None = None):
     return out
 
 
+def argmax_chunked(logits: torch.Tensor, keys: torch.Tensor, out: torch.Tensor, out2: torch.Tensor | None = None):
+    """argmax for a decode batch: rows cut into column ranges over many workgroups.  `keys` int64
+    [>= rows] must be zero before the first call (every call leaves it zero); `out2` gets the ids too."""
+    _dev(logits, "logits"), _dev(keys, "keys"), _dev(out, "out")
+    if logits.dtype not in _DT:
+        raise TypeError(f"logits dtype {logits.dtype} not supported")
+    B, V = logits.shape
+    for t, n in ((keys, "keys"), (out, "out")) + (((out2, "out2"),) if out2 is not None else ()):
+        if t.dtype != torch.int64 or t.numel() < B or not t.is_contiguous():
+            raise ValueError(f"{n} must be contiguous int64 with at least one element per row")
+    check(lib.mi355_argmax_chunked(out.data_ptr(), out2.data_ptr() if out2 is not None else 0, keys.data_ptr(),
+                                   logits.data_ptr(), _rows(logits, "logits"), B, V, _DT[logits.dtype], _stream()))
+    return out
+
+
+def embed_rms_norm(embed: torch.Tensor, token_ids: torch.Tensor, weight: torch.Tensor, eps: float,
+                   residual: torch.Tensor, out: torch.Tensor):
+    """residual <- embed[token_ids]; out <- rms_norm(residual): the first launch of a decode step."""
+    dt = _dt16(embed, "embed")
+    _dev(token_ids, "token_ids"), _dev(weight, "weight"), _dev(residual, "residual"), _dev(out, "out")
+    T = token_ids.numel()
+    H = embed.shape[1]
+    if token_ids.dtype != torch.int64 or not token_ids.is_contiguous():
+        raise ValueError("token_ids must be contiguous int64")
+    if weight.dtype != embed.dtype or weight.numel() != H or not weight.is_contiguous():
+        raise ValueError("weight must be contiguous [hidden] in the dtype of embed")
+    for t, n in ((residual, "residual"), (out, "out")):
+        if t.dtype != embed.dtype or tuple(t.shape) != (T, H):
+            raise ValueError(f"{n} must be [num_tokens, hidden] in the dtype of embed")
+    check(lib.mi355_embed_rms_norm(out.data_ptr(), residual.data_ptr(), embed.data_ptr(), token_ids.data_ptr(),
+                                   embed.shape[0], weight.data_ptr(), T, H, _rows(embed, "embed"), _rows(out, "out"),
+                                   _rows(residual, "residual"), float(eps), dt, _stream()))
+    return out
+
+
 def argmax_shard_key(logits: torch.Tensor, index_offset: int, out: torch.Tensor | None = None):
     """Key of the best token of a vocabulary slice whose first row is token `index_offset`:
     a signed 64-bit max over the slices' keys is the key of the argmax of the whole vocabulary
