@@ -243,11 +243,12 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
             async def sse():
                 try:
                     async for i, delta, reason, step_lp in events():
-                        if delta or reason is not None or step_lp is not None:
-                            chunk = {"id": cmpl_id, "object": "text_completion", "created": int(time.time()),
-                                     "model": served_model_name,
-                                     "choices": [{"index": i, "text": delta, "logprobs": step_lp, "finish_reason": reason}]}
-                            yield f"data: {json.dumps(chunk)}\n\n"
+                        # one event per generated token, as the engine this replaces streams them: the
+                        # text may be empty while the detokenizer holds back an unfinished UTF-8 sequence
+                        chunk = {"id": cmpl_id, "object": "text_completion", "created": int(time.time()),
+                                 "model": served_model_name,
+                                 "choices": [{"index": i, "text": delta, "logprobs": step_lp, "finish_reason": reason}]}
+                        yield f"data: {json.dumps(chunk)}\n\n"
                     yield "data: [DONE]\n\n"
                 except asyncio.CancelledError:
                     for rid in rids:
