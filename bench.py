@@ -311,6 +311,7 @@ def served_path(engine, cfg, a, batch):
     threading.Thread(target=results.serve_forever, daemon=True).start()
 
     name = "bench-model"
+    sys.setswitchinterval(float(os.environ.get("MI355_GIL_SWITCH_S", "0.0005")))   # as api_server.main does
     thread = EngineThread(lambda: engine)
     app = build_app(thread, name, load_tokenizer(a.model, cfg.vocab_size), cfg.vocab_size, a.prompt_len + a.gen_len)
     thread.start()

@@ -24,6 +24,13 @@ struct BF16 {
     __bf16 b = static_cast<__bf16>(f);  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
     return __builtin_bit_cast(uint16_t, b);
   }
+  // two floats -> two packed 16-bit values, one conversion instruction (RNE, as from_f)
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    const b2 r = __builtin_convertvector(f2{a, b}, b2);
+    return __builtin_bit_cast(uint32_t, r);
+  }
   static __device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
                                                    __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -44,6 +51,12 @@ struct F16 {
   static __device__ __forceinline__ uint16_t from_f(float f) {
     _Float16 h = static_cast<_Float16>(f);
     return __builtin_bit_cast(uint16_t, h);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    const h2 r = __builtin_convertvector(f2{a, b}, h2);
+    return __builtin_bit_cast(uint32_t, r);
   }
   static __device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
@@ -97,12 +110,7 @@ __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
 
 template <typename T>
 __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
-  uint32_t w[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    w[i] = static_cast<uint32_t>(T::from_f(f[2 * i])) |
-           (static_cast<uint32_t>(T::from_f(f[2 * i + 1])) << 16);
-  return make_uint4(w[0], w[1], w[2], w[3]);
+  return make_uint4(T::pack2(f[0], f[1]), T::pack2(f[2], f[3]), T::pack2(f[4], f[5]), T::pack2(f[6], f[7]));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

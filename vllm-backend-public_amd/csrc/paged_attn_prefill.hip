@@ -1,171 +1,281 @@
 // Prefill / chunked-prefill attention: causal attention of packed query chunks
 // over keys and values that are already in the paged KV cache.
 //
-// Work decomposition.  One 256-thread workgroup (4 waves) per
-// (16-query tile, kv head, sequence).  The tile's (query, head-in-group) pairs
-// -- 16 * group of them -- are laid on MFMA output COLUMNS, 16 per column tile;
-// wave w owns column tiles w*NQ .. w*NQ+NQ-1 and walks ALL keys the tile can see
-// in 32-token steps with an online softmax (no cross-wave merge; the four waves
-// read the same K/V pages, which hit in L1/L2 after the first touch).
+// Work decomposition.  One 256-thread workgroup (4 waves) per (query tile, kv head,
+// sequence).  A query tile is QT = 64*NQ / group consecutive queries; its (query,
+// head-in-group) pairs -- up to 64*NQ of them -- are laid on MFMA output COLUMNS, 16 per
+// column tile, and wave w owns column tiles w*NQ .. w*NQ+NQ-1 (NQ = 1 or 2 by the chunk
+// length; 4 is built).  The workgroup walks the keys its tile can see in 32-token steps.  The
+// K and V pages of a step are STAGED THROUGH LDS ONCE PER WORKGROUP, double buffered: all 256
+// threads copy the two pages (coalesced 16-byte pieces, whole 4 KB pages) into an LDS image
+// in FRAGMENT ORDER -- piece (fragment, lane) at (fragment*64 + lane)*16, so every wave's
+// `ds_read_b128` of an MFMA A operand is lane-linear and conflict-free -- while the waves
+// compute on the other buffer; one workgroup barrier per step.  The query fragments (B
+// operands) sit in LDS as well.  Softmax in two passes over the keys: the first finds every
+// column's maximum score (QK^T MFMAs only), the second forms p = exp2(s*scale - max) and
+// O += V^T P^T with no rescaling -- the loop bodies are straight lines, O never leaves the
+// accumulation registers, and the QK^T MFMAs are paid twice (an online softmax with 16 columns
+// per tile moves its running maximum in most steps; every move rescales all of O, and the
+// compiler then shuttled the 128 registers of O between register files at EVERY step).
 //
-// MFMA mapping is the decode kernel's (paged_attn_decode.hip): S^T = K . Q^T
-// with K rows loaded straight from the page into the A operand, and
-// O^T += V^T . P^T with the transposed V page as the A operand and the lane's
-// own probabilities as B.  The causal mask is applied per column
-// (key <= position of the column's query).  MFMA-bound in principle; this
-// version re-reads K/V through L1 per wave and is tuned for correctness first.
+// MFMA mapping is the decode kernel's (paged_attn_decode.hip): S^T = K . Q^T with the K
+// rows as the A operand, and O^T += V^T . P^T with the transposed V page as the A operand
+// and the lane's own probabilities as B.  The causal mask is applied per column (key <=
+// position of the column's query).  Latency-bound at 1-2 workgroups per CU: measured 326
+// TFLOP/s on 16 x 2048 tokens (13 % of the bf16 MFMA peak).
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
+#include <type_traits>
 
 namespace mi355 {
 
 constexpr int kPrefillThreads = 256;
-constexpr int kQTile = 16;
+constexpr int kPrefillWaves = kPrefillThreads / 64;
 
 template <typename T, int D, int NQ>
 __global__ __launch_bounds__(kPrefillThreads) void paged_attn_prefill_kernel(
     uint16_t* __restrict__ out, int64_t out_stride, const uint16_t* __restrict__ q, int64_t q_stride,
     const uint16_t* __restrict__ k_cache, const uint16_t* __restrict__ v_cache, int num_blocks,
     const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ cu_seqlens,
-    const int32_t* __restrict__ context_lens, int num_heads, int num_kv_heads, float scale_log2e) {
+    const int32_t* __restrict__ context_lens, int num_heads, int num_kv_heads, float scale_log2e, int qt) {
   constexpr int KS = D / 32;
   constexpr int NT = D / 16;
   constexpr int BS = MI355_BLOCK_SIZE;
+  // K image of a step: [tile a/b][k-step][h = lane >> 4][c = lane & 15][16 B], each 16-lane block
+  // followed by 16 B of padding: eight consecutive staging threads write eight (k-step, h) slots
+  // of one row, and 272-byte / 1088-byte strides put those on eight different 16-byte bank groups
+  constexpr int KFRAG = 4 * 272;
+  constexpr int KBYTES = 2 * KS * KFRAG;
+  constexpr int VBYTES = NT * 1024;              // V image: [16-row tile of head_dim][lane][16 B]
+  constexpr int BUF = KBYTES + VBYTES;
+  constexpr int PIECES = 8 * D;                  // 16-byte pieces per step: two K pages + two V pages
+  constexpr int PPT = PIECES / kPrefillThreads;  // per thread: 4 (D = 128) or 2 (D = 64)
+  static_assert(PIECES % kPrefillThreads == 0, "whole pieces per thread");
+  // the wave's query fragments (B operands) live in LDS too, [wave][column tile][k-step][lane][16 B]:
+  // 16 KB per wave at NQ = 4 would otherwise be 64 registers per lane on top of the 128 of O
+  constexpr int QBYTES = kPrefillWaves * NQ * KS * 1024;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + QBYTES];
 
   const int qtile = blockIdx.x, kvh = blockIdx.y, seq = blockIdx.z;
   const int group = num_heads / num_kv_heads;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, h = lane >> 4;
 
   const int q_begin = cu_seqlens[seq];
   const int q_len = cu_seqlens[seq + 1] - q_begin;
-  const int q0 = qtile * kQTile;
-  if (q0 >= q_len) return;
+  const int q0 = qtile * qt;
+  if (q0 >= q_len) return;                       // whole workgroup: no barrier is skipped by some threads only
   int ctx = context_lens[seq];
   const int ctx_cap = max_blocks * BS;
   ctx = ctx > ctx_cap ? ctx_cap : ctx;
-  const int pos0 = ctx - q_len;  // absolute position of the chunk's first query
-  if (pos0 < 0) return;          // inconsistent lengths: nothing sensible to compute
+  const int pos0 = ctx - q_len;                  // absolute position of the chunk's first query
+  if (pos0 < 0) return;                          // inconsistent lengths: nothing sensible to compute
 
   // this lane's columns: pair index p = (wave*NQ + t)*16 + c -> (query, head)
   int col_q[NQ], col_head[NQ], col_pos[NQ];
   bool col_ok[NQ];
-  uint4 qf[NQ][KS];
+  unsigned char* qlds = &lds[2 * BUF + wave * (NQ * KS * 1024) + lane * 16];   // this lane's slot of fragment 0
 #pragma unroll
   for (int t = 0; t < NQ; ++t) {
     const int p = (wave * NQ + t) * 16 + c;
     col_q[t] = q0 + p / group;
     col_head[t] = kvh * group + p % group;
-    col_ok[t] = (p < kQTile * group) && (col_q[t] < q_len);
+    col_ok[t] = (p < qt * group) && (col_q[t] < q_len);
     col_pos[t] = col_ok[t] ? pos0 + col_q[t] : -1;
-    if (col_ok[t]) {
-      const uint16_t* qp =
-          q + (q_begin + col_q[t]) * q_stride + static_cast<int64_t>(col_head[t]) * D + 8 * h;
+    const uint16_t* qp = q + (q_begin + (col_ok[t] ? col_q[t] : 0)) * q_stride +
+                         static_cast<int64_t>(col_ok[t] ? col_head[t] : 0) * D + 8 * h;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) qf[t][ks] = *reinterpret_cast<const uint4*>(qp + 32 * ks);
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) qf[t][ks] = make_uint4(0, 0, 0, 0);
+    for (int ks = 0; ks < KS; ++ks) {
+      const uint4 v = *reinterpret_cast<const uint4*>(qp + 32 * ks);     // always a valid row; dropped if not ours
+      *reinterpret_cast<uint4*>(qlds + (t * KS + ks) * 1024) = col_ok[t] ? v : make_uint4(0, 0, 0, 0);
     }
   }
-  // keys this wave needs: up to the largest position among its columns
-  int kmax = -1;
+  int kmin = 0x7FFFFFFF;                                         // smallest position among the wave's valid columns
 #pragma unroll
-  for (int t = 0; t < NQ; ++t) kmax = max(kmax, col_pos[t]);
+  for (int t = 0; t < NQ; ++t) kmin = min(kmin, col_ok[t] ? col_pos[t] : 0x7FFFFFFF);
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, 64));
-  const int t_end = kmax + 1;  // wave-uniform; 0 when the wave has no valid column
+  for (int off = 32; off > 0; off >>= 1) kmin = min(kmin, __shfl_xor(kmin, off, 64));
+  const int t_min = __builtin_amdgcn_readfirstlane(kmin);
+  const int t_end_wg = pos0 + min(q0 + qt, q_len);              // the tile's last query sees keys [0, t_end_wg)
 
-  float m[NQ], l[NQ];
+  const int32_t* bt = block_tables + static_cast<int64_t>(seq) * max_blocks;
+  const int last_blk_idx = (t_end_wg - 1) / BS;                 // t_end_wg >= 1
+
+  // ---- staging: thread tid copies pieces g = j*256 + tid of a step (j < PPT/2: the two K pages,
+  // the rest: the two V pages).  Source addresses walk a page front to back (coalesced);
+  // destinations are in fragment order.
+  int src_page[PPT], dst_off[PPT];
+  int64_t src_off[PPT];                                          // element offset inside the (block, kv head) page
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int g = j * kPrefillThreads + tid;
+    if (j < PPT / 2) {                                           // K: [page][row 0..15][16-byte slot 0..D/8)
+      const int pg = g / (2 * D), rem = g % (2 * D);
+      const int r = rem / (D / 8), sl = rem % (D / 8);
+      const int ks = sl >> 2, hh = sl & 3;
+      const int tile = (r >> 2) & 1;
+      const int cc = (r & 3) | (((r >> 3) & 1) << 2) | (pg << 3);
+      src_page[j] = pg;
+      src_off[j] = r * D + sl * 8;
+      dst_off[j] = (tile * KS + ks) * KFRAG + hh * 272 + cc * 16;
+    } else {                                                     // V: [page][head_dim row][half of the 16 tokens]
+      const int g2 = g - PIECES / 2;
+      const int pg = g2 / (2 * D), rem = g2 % (2 * D);
+      const int dr = rem >> 1, half = rem & 1;
+      src_page[j] = pg;
+      src_off[j] = dr * BS + half * 8;
+      dst_off[j] = KBYTES + ((dr >> 4) * 64 + (pg * 2 + half) * 16 + (dr & 15)) * 16;
+    }
+  }
+  typedef unsigned int pvec __attribute__((ext_vector_type(4)));
+  // NP = PPT / 2: the K pages only (first pass); NP = PPT: K and V
+  auto stage_load = [&](pvec (&regs)[PPT], int tb, auto np) {
+    constexpr int NP = decltype(np)::value;
+    const int bi = min(tb / BS, last_blk_idx);
+    int blk[2] = {bt[bi], bt[min(bi + 1, last_blk_idx)]};
+    blk[0] = min(max(blk[0], 0), num_blocks - 1);
+    blk[1] = min(max(blk[1], 0), num_blocks - 1);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int64_t page = (static_cast<int64_t>(blk[src_page[j]]) * num_kv_heads + kvh) * (BS * D);
+      const uint16_t* src = (j < PPT / 2 ? k_cache : v_cache) + page + src_off[j];
+      regs[j] = *reinterpret_cast<const pvec*>(src);
+    }
+  };
+  auto stage_store = [&](const pvec (&regs)[PPT], int buf, auto np) {
+    constexpr int NP = decltype(np)::value;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) *reinterpret_cast<pvec*>(&lds[buf * BUF + dst_off[j]]) = regs[j];
+  };
+  const std::integral_constant<int, PPT / 2> k_only;
+  const std::integral_constant<int, PPT> k_and_v;
+
+  const int steps = (t_end_wg + 31) / 32;
+  const int tok_h = 8 * h;
+
+  // S^T = K . Q^T of one step for all column tiles (a K fragment is read from LDS once and used NQ
+  // times), causal mask applied where the step reaches past some column of this wave
+  auto scores = [&](int s, f32x4 (&sa)[NQ], f32x4 (&sb)[NQ]) {
+    const unsigned char* base = &lds[(s & 1) * BUF + lane * 16 + 16 * h];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) sa[t] = sb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const uint4 ka = *reinterpret_cast<const uint4*>(base + ks * KFRAG);
+      const uint4 kb = *reinterpret_cast<const uint4*>(base + (KS + ks) * KFRAG);
+#pragma unroll
+      for (int t = 0; t < NQ; ++t) {
+        const uint4 qf = *reinterpret_cast<const uint4*>(qlds + (t * KS + ks) * 1024);   // written by this same lane
+        sa[t] = T::mfma(ka, qf, sa[t]);
+        sb[t] = T::mfma(kb, qf, sb[t]);
+      }
+    }
+    const int tok0 = s * 32 + tok_h;
+    if (s * 32 + 32 > t_min + 1) {         // wave-uniform: on or beyond the diagonal for some column
+#pragma unroll
+      for (int t = 0; t < NQ; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sa[t][j] = (tok0 + j <= col_pos[t]) ? sa[t][j] : -INFINITY;
+          sb[t][j] = (tok0 + 4 + j <= col_pos[t]) ? sb[t][j] : -INFINITY;
+        }
+      }
+    }
+  };
+
+  // ================= pass 1: the maximum score of every column =================
+  // Two passes instead of an online softmax: with 16 columns per tile a running maximum moves in
+  // most steps, and every move rescales the 128 accumulator registers of O (which the compiler
+  // then also keeps shuttling between register files).  The first pass costs the QK^T MFMAs a
+  // second time (half of all MFMAs) and leaves the second pass a straight line: scores, one fma +
+  // exp2 per score, PV.
+  float mx[NQ];
+#pragma unroll
+  for (int t = 0; t < NQ; ++t) mx[t] = -INFINITY;
+  {
+    pvec r0[PPT];
+    stage_load(r0, 0, k_only);
+    stage_store(r0, 0, k_only);
+  }
+  __syncthreads();
+  for (int s = 0; s < steps; ++s) {
+    const bool more = s + 1 < steps;
+    pvec nxt[PPT];
+    if (more) stage_load(nxt, s * 32 + 32, k_only);             // workgroup-uniform branch
+    f32x4 sa[NQ], sb[NQ];
+    scores(s, sa, sb);
+#pragma unroll
+    for (int t = 0; t < NQ; ++t)
+      mx[t] = fmaxf(mx[t], fmaxf(fmaxf(fmaxf(sa[t][0], sa[t][1]), fmaxf(sa[t][2], sa[t][3])),
+                                 fmaxf(fmaxf(sb[t][0], sb[t][1]), fmaxf(sb[t][2], sb[t][3]))));
+    if (more) stage_store(nxt, (s + 1) & 1, k_only);
+    __syncthreads();                                             // also before the second pass refills buffer 0
+  }
+  float neg_m[NQ], l[NQ];
   f32x4 o[NQ][NT];
 #pragma unroll
   for (int t = 0; t < NQ; ++t) {
-    m[t] = -INFINITY;
+    float v = mx[t];
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    neg_m[t] = (v == -INFINITY) ? 0.f : -(v * scale_log2e);      // a column that sees no key: exponent reference 0
     l[t] = 0.f;
 #pragma unroll
     for (int n = 0; n < NT; ++n) o[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  const int32_t* bt = block_tables + static_cast<int64_t>(seq) * max_blocks;
-  const int last_blk_idx = t_end > 0 ? (t_end - 1) / BS : 0;
-  const int koff = ((c >> 2) & 1) * 8 + (c & 3);
-
-  for (int tb = 0; tb < t_end; tb += 32) {
-    const int bi = tb / BS;
-    int blk0 = bt[bi];
-    int blk1 = bt[min(bi + 1, last_blk_idx)];
-    blk0 = min(max(blk0, 0), num_blocks - 1);
-    blk1 = min(max(blk1, 0), num_blocks - 1);
-
-    const int kblk = (c & 8) ? blk1 : blk0;
-    const uint16_t* kp =
-        k_cache + ((static_cast<int64_t>(kblk) * num_kv_heads + kvh) * BS + koff) * D + 8 * h;
-    uint4 ka[KS], kb[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      ka[ks] = *reinterpret_cast<const uint4*>(kp + 32 * ks);
-      kb[ks] = *reinterpret_cast<const uint4*>(kp + 4 * D + 32 * ks);
-    }
-    const int vblk = (h & 2) ? blk1 : blk0;
-    const uint16_t* vp =
-        v_cache + ((static_cast<int64_t>(vblk) * num_kv_heads + kvh) * D + c) * BS + 8 * (h & 1);
-    uint4 vf[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) vf[n] = *reinterpret_cast<const uint4*>(vp + n * 16 * BS);
-
-    const int tok0 = tb + 8 * h;
-    if (tb + 32 > t_end) {  // clear V columns of tokens no column can see (may be unwritten)
-      uint32_t msk[4];
-#pragma unroll
-      for (int w = 0; w < 4; ++w)
-        msk[w] = ((tok0 + 2 * w < t_end) ? 0x0000FFFFu : 0u) | ((tok0 + 2 * w + 1 < t_end) ? 0xFFFF0000u : 0u);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        vf[n].x &= msk[0];
-        vf[n].y &= msk[1];
-        vf[n].z &= msk[2];
-        vf[n].w &= msk[3];
-      }
-    }
-
+  // ================= pass 2: probabilities and O =================
+  {
+    pvec r0[PPT];
+    stage_load(r0, 0, k_and_v);
+    stage_store(r0, 0, k_and_v);
+  }
+  __syncthreads();
+  for (int s = 0; s < steps; ++s) {
+    const bool more = s + 1 < steps;
+    pvec nxt[PPT];
+    if (more) stage_load(nxt, s * 32 + 32, k_and_v);
+    f32x4 sa[NQ], sb[NQ];
+    scores(s, sa, sb);
+    // p = exp2(s * scale - max) <= 1: the softmax scale is folded into the exponent, one fma per score
+    uint4 pf[NQ];
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
-      f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        sa = T::mfma(ka[ks], qf[t][ks], sa);
-        sb = T::mfma(kb[ks], qf[t][ks], sb);
-      }
-      float s[8];
+      float p[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        s[j] = (tok0 + j <= col_pos[t]) ? sa[j] * scale_log2e : -INFINITY;
-        s[4 + j] = (tok0 + 4 + j <= col_pos[t]) ? sb[j] * scale_log2e : -INFINITY;
+        p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[t][j], scale_log2e, neg_m[t]));
+        p[4 + j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sb[t][j], scale_log2e, neg_m[t]));
       }
-      float mx = s[0];
+      l[t] += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+      pf[t] = pack8<T>(p);
+    }
+    // O^T += V^T . P^T: a V fragment is read once and used NQ times.  In the tile's last step the V
+    // columns of tokens beyond its last query may be unwritten (0 * NaN): cleared by a mask that is
+    // all ones in every other step.
+    const int tok0 = s * 32 + tok_h;
+    uint32_t msk[4];
 #pragma unroll
-      for (int j = 1; j < 8; ++j) mx = fmaxf(mx, s[j]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      // a column whose keys are all masked in this step keeps its state
-      const float m_new = fmaxf(m[t], mx);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = exp2f(m[t] - m_use);
-      float p[8], psum = 0.f;
+    for (int w = 0; w < 4; ++w)
+      msk[w] = ((tok0 + 2 * w < t_end_wg) ? 0x0000FFFFu : 0u) | ((tok0 + 2 * w + 1 < t_end_wg) ? 0xFFFF0000u : 0u);
+    const unsigned char* vbase = &lds[(s & 1) * BUF + KBYTES + lane * 16];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        p[j] = exp2f(s[j] - m_use);
-        psum += p[j];
-      }
-      l[t] = l[t] * alpha + psum;
-      m[t] = m_new;
-      const uint4 pf = pack8<T>(p);
+    for (int n = 0; n < NT; ++n) {
+      uint4 vf = *reinterpret_cast<const uint4*>(vbase + n * 1024);
+      vf.x &= msk[0];
+      vf.y &= msk[1];
+      vf.z &= msk[2];
+      vf.w &= msk[3];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        o[t][n] *= alpha;
-        o[t][n] = T::mfma(vf[n], pf, o[t][n]);
-      }
+      for (int t = 0; t < NQ; ++t) o[t][n] = T::mfma(vf, pf[t], o[t][n]);
+    }
+    if (more) {
+      stage_store(nxt, (s + 1) & 1, k_and_v);
+      __syncthreads();
     }
   }
 
@@ -222,20 +332,30 @@ extern "C" int32_t mi355_paged_attn_prefill(void* out, int64_t out_stride, const
                 "%s: dtype %d not supported (bf16/fp16 only)", name, dtype);
   if (num_seqs == 0 || max_q_len == 0) return MI355_OK;
 
-  const int nq = (kQTile * group + 63) / 64;  // column tiles per wave: 1..4
-  dim3 grid((max_q_len + kQTile - 1) / kQTile, num_kv_heads, num_seqs), block(kPrefillThreads);
+  // column tiles per wave: a workgroup covers 64*nq (query, head) pairs.  Two, not four, beyond
+  // short chunks: the kernel is bound by the latency chain of a step (LDS reads -> MFMAs -> exp ->
+  // MFMAs -> barrier), and at nq = 2 two workgroups share a CU (66 KB of LDS, 168 registers) and
+  // overlap their chains -- measured on 16 x 2048 tokens, 8 heads on one kv head: 422 us against
+  // 569 us at nq = 4 and 471 us at nq = 1.  MI355_PREFILL_NQ=4 selects the wide form for experiments.
+  const int64_t pairs = static_cast<int64_t>(max_q_len) * group;
+  int nq = pairs <= 64 ? 1 : 2;
+  if (const char* e = getenv("MI355_PREFILL_NQ")) {
+    const int want = atoi(e);
+    if (want == 1 || want == 2 || want == 4) nq = (pairs <= 64 && want > 1) ? nq : want;
+  }
+  const int qt = 64 * nq / group;                      // queries per workgroup (>= 4: group <= 16)
+  dim3 grid((max_q_len + qt - 1) / qt, num_kv_heads, num_seqs), block(kPrefillThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define MI355_PRE(TT, DD, NN)                                                                           \
   hipLaunchKernelGGL((paged_attn_prefill_kernel<TT, DD, NN>), grid, block, 0, s,                        \
                      static_cast<uint16_t*>(out), out_stride, static_cast<const uint16_t*>(q), q_stride, \
                      static_cast<const uint16_t*>(k_cache), static_cast<const uint16_t*>(v_cache),      \
                      num_blocks, block_tables, max_blocks_per_seq, cu_seqlens, context_lens, num_heads, \
-                     num_kv_heads, scale * 1.4426950408889634f)
+                     num_kv_heads, scale * 1.4426950408889634f, qt)
 #define MI355_PRE_NQ(TT, DD)                \
   switch (nq) {                             \
     case 1: MI355_PRE(TT, DD, 1); break;    \
     case 2: MI355_PRE(TT, DD, 2); break;    \
-    case 3: MI355_PRE(TT, DD, 3); break;    \
     default: MI355_PRE(TT, DD, 4); break;   \
   }
   if (dtype == MI355_BF16) {

@@ -5,7 +5,11 @@ north-star metric needs.  B concurrent streaming token-id requests (`ignore_eos`
 
     TTFT            = t_first_token - t_submit                      (p50 over the B requests)
     decode tok/s    = B * (G - 1) / (t_last_token - t_first_token)  (first token of the earliest
-                      request to last token of the latest: whole-batch rate)
+                      request to last token of the latest: whole-batch rate; requests that arrive a
+                      few ms apart are prefilled in several steps, and that stagger is inside it)
+    steady tok/s    = tokens received while ALL B streams are decoding (after the latest first
+                      token, up to the earliest last token) / that window: the served decode rate
+                      without the ramp at either end
 
 One untimed warm-up run, then `runs` measured runs; the medians are reported and, when a results
 URL is given, posted as an EvaluationPayload to /raw_input and /standardized_output
@@ -40,6 +44,7 @@ async def _one(session, url: str, model: str, prompt: List[int], gen: int, t_sta
     t_submit = time.perf_counter()
     first = last = None
     chunks = 0
+    stamps = []
     async with session.post(url + "/v1/completions", json=body) as r:
         if r.status != 200:
             raise RuntimeError(f"HTTP {r.status}: {await r.text()}")
@@ -58,7 +63,9 @@ async def _one(session, url: str, model: str, prompt: List[int], gen: int, t_sta
             if first is None:
                 first = now
             last = now
-    return {"submit": t_submit - t_start, "first": first - t_start, "last": last - t_start, "chunks": chunks}
+            stamps.append(now - t_start)
+    return {"submit": t_submit - t_start, "first": first - t_start, "last": last - t_start, "chunks": chunks,
+            "stamps": stamps}
 
 
 async def one_run(url: str, model: str, prompts: List[List[int]], gen: int):
@@ -71,7 +78,10 @@ async def one_run(url: str, model: str, prompts: List[List[int]], gen: int):
     B = len(prompts)
     ttft = [r["first"] - r["submit"] for r in res]
     t_first, t_last = min(r["first"] for r in res), max(r["last"] for r in res)
-    return {"ttft_ms_p50": statistics.median(ttft) * 1e3, "ttft_ms_max": max(ttft) * 1e3,
+    t_a, t_b = max(r["first"] for r in res), min(r["last"] for r in res)
+    inside = sum(1 for r in res for t in r["stamps"] if t_a < t <= t_b)
+    return {"steady_tok_s": inside / (t_b - t_a) if t_b > t_a else 0.0,
+            "ttft_ms_p50": statistics.median(ttft) * 1e3, "ttft_ms_max": max(ttft) * 1e3,
             "decode_tok_s": B * (gen - 1) / (t_last - t_first) if t_last > t_first else 0.0,
             "wall_s": t_last, "chunks_min": min(r["chunks"] for r in res)}
 
@@ -109,6 +119,7 @@ def main(argv=None) -> int:
            "decode_tok_s_p50": round(statistics.median(r["decode_tok_s"] for r in runs), 1),
            "ttft_ms_p50": round(statistics.median(r["ttft_ms_p50"] for r in runs), 2),
            "ttft_ms_max_p50": round(statistics.median(r["ttft_ms_max"] for r in runs), 2),
+           "steady_decode_tok_s_p50": round(statistics.median(r["steady_tok_s"] for r in runs), 1),
            "decode_tok_s_runs": [round(r["decode_tok_s"], 1) for r in runs],
            "chunks_per_request_min": min(r["chunks_min"] for r in runs)}
     if a.results_url:

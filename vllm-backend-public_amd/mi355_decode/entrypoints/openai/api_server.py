@@ -165,7 +165,8 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
         q: asyncio.Queue = asyncio.Queue()
         rids = [f"{cmpl_id}-{i}" for i in range(len(prompts))]
         for i, (rid, p) in enumerate(zip(rids, prompts)):
-            engine_thread.submit(rid, p, params, lambda o, i=i: loop.call_soon_threadsafe(q.put_nowait, (i, o)))
+            # the sink runs on this request's loop; a step's outputs for one loop arrive in one wake-up
+            engine_thread.submit(rid, p, params, lambda o, i=i: q.put_nowait((i, o)), loop=loop)
 
         detoks = [IncrementalDetokenizer(tokenizer) for _ in prompts]
         texts = [tokenizer.decode(p) if echo else "" for p in prompts]
@@ -302,6 +303,9 @@ def main(argv: Optional[List[str]] = None) -> int:
                         os.environ.get("VLLM_LOGGING_LEVEL", "INFO").upper() in ("DEBUG", "INFO", "WARNING", "ERROR")
                         else "INFO", format="%(asctime)s %(levelname)s %(name)s: %(message)s")
     argv = list(sys.argv[1:] if argv is None else argv)
+    # the engine thread and the HTTP loop share one interpreter: hand the lock over quickly, or a
+    # decode step waits for the SSE writer's time slice
+    sys.setswitchinterval(float(os.environ.get("MI355_GIL_SWITCH_S", "0.0005")))
     removed = sanitize_env()
     if removed:
         log.info("ignoring harness-set %s (GPU visibility comes from the device plugin)", removed)

@@ -50,6 +50,7 @@ class EngineThread:
         self.stop_flag = False
         self.control_group, self.rank = control_group, rank
         self.thread = threading.Thread(target=self._run, name="mi355-engine", daemon=True)
+        self.sink_loops = {}                 # request_id -> asyncio loop its sink must run on (or absent)
         self.steps = 0
         self.tokens_out = 0
         self.started = time.time()
@@ -58,12 +59,18 @@ class EngineThread:
         self.thread.start()
 
     # ---- called from the server thread ---------------------------------- #
-    def submit(self, request_id: str, prompt_ids: List[int], params: SamplingParams, sink) -> None:
+    def submit(self, request_id: str, prompt_ids: List[int], params: SamplingParams, sink, loop=None) -> None:
+        """`sink(RequestOutput | Exception)` is called from the engine thread, or -- with `loop` -- on
+        that asyncio loop's thread: all outputs of one engine step that go to one loop are handed
+        over with a single thread-safe wake-up."""
+        if loop is not None:
+            self.sink_loops[request_id] = loop
         self.sinks[request_id] = sink
         self.inbox.put(_Add(request_id, prompt_ids, params, time.perf_counter()))
 
     def abort(self, request_id: str) -> None:
         self.sinks.pop(request_id, None)
+        self.sink_loops.pop(request_id, None)
         self.inbox.put(_Abort(request_id))
 
     def shutdown(self):
@@ -104,6 +111,26 @@ class EngineThread:
         dist.broadcast(buf, src=0, group=self.control_group)
         return msgs if self.rank == 0 else pickle.loads(buf.numpy().tobytes())
 
+    def _deliver(self, batch) -> None:
+        """batch: (request_id, sink, output) triples of one engine step."""
+        groups = {}
+        for rid, sink, o in batch:
+            loop = self.sink_loops.get(rid)
+            if getattr(o, "finished", True):              # last output (or an exception): forget the loop
+                self.sink_loops.pop(rid, None)
+            if loop is None:
+                sink(o)
+            else:
+                groups.setdefault(loop, []).append((sink, o))
+        for loop, items in groups.items():
+            def run(items=items):
+                for sink, o in items:
+                    sink(o)
+            try:
+                loop.call_soon_threadsafe(run)
+            except RuntimeError:                          # the client's loop is gone: nobody is listening
+                pass
+
     def _run(self):
         try:
             self.engine = self._make_engine()
@@ -123,27 +150,28 @@ class EngineThread:
                         except Exception as exc:         # bad request: report to its sink only
                             sink = self.sinks.pop(m.request_id, None)
                             if sink:
-                                sink(exc)
+                                self._deliver([(m.request_id, sink, exc)])
                     elif isinstance(m, _Abort):
                         eng.abort_request(m.request_id)
                 if not eng.has_unfinished():
                     continue
                 outs: List[RequestOutput] = eng.step()
                 self.steps += 1
+                batch = []
                 for o in outs:
                     self.tokens_out += len(o.new_token_ids)
                     sink = self.sinks.get(o.request_id)
                     if sink:
-                        sink(o)
+                        batch.append((o.request_id, sink, o))
                         if o.finished:
                             self.sinks.pop(o.request_id, None)
+                self._deliver(batch)
         except BaseException as exc:                     # fatal: surface on /health and to waiters
             log.exception("engine thread died")
             self.failed = exc
             self.ready.set()
-            for sink in list(self.sinks.values()):
-                try:
-                    sink(exc)
-                except Exception:
-                    pass
+            try:
+                self._deliver([(rid, sink, exc) for rid, sink in list(self.sinks.items())])
+            except Exception:
+                pass
             self.sinks.clear()
