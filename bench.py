@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eager", action="store_true", help="debug only: no HIP graphs")
+    ap.add_argument("--oneshot-allreduce", action="store_true",
+                    help="N > 1: the hand-written one-shot all-reduce for the decode-sized messages instead of RCCL "
+                         "(same as MI355_ONESHOT_ALLREDUCE=1)")
     ap.add_argument("--segments", type=int, default=5,
                     help="timed regions of exactly --steps steps each; the median one is reported")
     ap.add_argument("--no-served", action="store_true", help="skip the measurement through the HTTP server")
@@ -379,6 +382,8 @@ def main():
     batch = a.batch_per_gpu * a.gpus
     P, G = a.prompt_len, a.gen_len
 
+    if a.oneshot_allreduce:
+        os.environ["MI355_ONESHOT_ALLREDUCE"] = "1"
     cfg = ModelConfig.from_pretrained(a.model)
     args = EngineArgs(model=a.model, dtype=a.dtype, max_num_seqs=batch, max_model_len=P + G,
                       max_num_batched_tokens=max(8192, 1), tensor_parallel_size=tp, load_format="dummy",
@@ -516,6 +521,8 @@ def main():
     r_ = engine.runner
     result["degraded"] = {"hip_graphs": bool(r_.use_graphs), "graph_capture_failures": r_.capture_failures,
                           "gemm_tune_failures": r_.tune_failures,
+                          "allreduce": ("none (1 GPU)" if tp == 1 else
+                                        "one-shot kernel over IPC-mapped buffers" if r_.oneshot is not None else "RCCL"),
                           "gemm_form": {k: ("tiled" if v else "library") for k, v in r_._mode(batch).items()}}
 
     kern = None

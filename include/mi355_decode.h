@@ -479,6 +479,37 @@ int32_t mi355_linear_tiled_w8(void* y, int64_t y_stride, void* partial,
                               int32_t tiles_per_wg, int32_t k_groups,
                               int32_t epilogue, int32_t dtype, void* stream);
 
+/*
+ * One-shot all-reduce (sum, in place) of the small 16-bit messages of a tensor-parallel decode
+ * step: the [tokens, hidden] partial sums after the attention output projection (and after the
+ * down projection when the MLP is sharded), one process per GPU.  Every rank writes its message
+ * into a buffer of every peer (mapped through HIP IPC), flags it, waits for the peers' flags and
+ * adds the world messages in rank order in fp32 -- one kernel per call, no host round trip,
+ * results bit-identical on all ranks, capturable into a HIP graph.  Replaces what the engine
+ * image does with its custom all-reduce for these sizes (the harness switches that one off:
+ * --disable-custom-all-reduce, benchmark-vllm/vllm_templates.py:62, VLLM_DISABLE_CUSTOM_ALL_REDUCE
+ * :157-160, so the collective is this engine's own business).
+ *   init     allocates this rank's buffer (uncached device memory: 2 * world * max_bytes + flags)
+ *            and writes its IPC handle (mi355_allreduce_oneshot_handle_bytes() bytes) to
+ *            handle_out; the caller gathers the handles of all ranks (any transport)
+ *   connect  maps the peers' buffers; all_handles = world handles in rank order
+ *   run      data: count 16-bit elements on this rank's GPU (count % 8 == 0, count * 2 <=
+ *            max_bytes), summed over the ranks in place.  Every rank must issue the same calls
+ *            with the same counts in the same order.  A peer that does not arrive within 2 s
+ *            makes the kernel give up and leave data as it was:
+ *   status   synchronises with the queued work and returns MI355_ERR_LAUNCH if that happened
+ *   destroy  unmaps and frees
+ * world <= 8, max_bytes <= 16 MiB.  Larger (prefill-sized) messages belong on RCCL.
+ */
+int64_t mi355_allreduce_oneshot_handle_bytes(void);
+int32_t mi355_allreduce_oneshot_init(void** comm_out, int32_t rank, int32_t world,
+                                     int64_t max_bytes, void* handle_out);
+int32_t mi355_allreduce_oneshot_connect(void* comm, const void* all_handles);
+int32_t mi355_allreduce_oneshot_run(void* comm, void* data, int64_t count,
+                                    int32_t dtype, void* stream);
+int32_t mi355_allreduce_oneshot_status(void* comm);
+int32_t mi355_allreduce_oneshot_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

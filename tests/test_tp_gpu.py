@@ -2,7 +2,8 @@
 TP=2 group) share the card and exchange their partial sums over gloo -- RCCL refuses two
 ranks on one device, and gloo cannot be graph-captured, so the steps run eagerly.  What is
 pinned: the head, MLP and vocabulary sharding of the weights, both all-reduce call sites,
-the key max-reduce of greedy sampling and the gather of whole rows for random sampling, the
+(over gloo, and through the hand-written one-shot all-reduce over IPC-mapped buffers), the
+key max-reduce of greedy sampling and the gather of whole rows for random sampling, the
 lock-step of the two schedulers, and the generated tokens against the numpy oracle of the
 unsharded model (a sharded sum rounds differently: a sequence may leave the oracle at a
 near-tie of the oracle's own logits, as in test_model_gpu)."""
@@ -28,7 +29,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, name, dtype, shard_mlp, q):
+def _worker(rank, world, port, name, dtype, shard_mlp, q, oneshot=False):
     import faulthandler
     faulthandler.dump_traceback_later(80, exit=True)      # a rank stuck in a collective says where, then leaves
     try:
@@ -37,7 +38,7 @@ def _worker(rank, world, port, name, dtype, shard_mlp, q):
                 sys.path.insert(0, p)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                           LOCAL_RANK="0", MI355_DIST_BACKEND="gloo", MI355_TP_MLP="1" if shard_mlp else "0",
-                          MI355_TP_VOCAB="1" if shard_mlp else "0")
+                          MI355_TP_VOCAB="1" if shard_mlp else "0", MI355_ONESHOT_ALLREDUCE="1" if oneshot else "0")
         import torch
         import torch.distributed as dist
         from test_model_gpu import build, engine_generate
@@ -57,6 +58,11 @@ def _worker(rank, world, port, name, dtype, shard_mlp, q):
         steps = eng.stats["decode_steps"] + eng.stats["prefill_steps"]
         per_step = r.L * (2 if shard_mlp else 1)               # a step launched ahead may not be counted yet
         assert calls[0] % per_step == 0 and calls[0] >= steps * per_step, (calls[0], steps)
+        if oneshot:                                             # every message of these tiny models fits the one-shot kernel
+            assert r.oneshot is not None and r.oneshot_calls == calls[0], (r.oneshot_calls, calls[0])
+            r.oneshot.check()
+        else:
+            assert r.oneshot is None
         # random sampling and log-probabilities need whole rows: gathered from the ranks' slices
         from mi355_decode.sampling_params import SamplingParams
         sampled = {}
@@ -88,9 +94,10 @@ def _worker(rank, world, port, name, dtype, shard_mlp, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shard_mlp", [True, False], ids=["mlp_sharded", "mlp_replicated"])
+@pytest.mark.parametrize("shard_mlp,oneshot", [(True, False), (False, False), (True, True)],
+                         ids=["mlp_sharded", "mlp_replicated", "mlp_sharded_oneshot_allreduce"])
 @pytest.mark.parametrize("name,dtype", [("llama_d128", "bfloat16"), ("qwen2_d128", "float16")])
-def test_two_ranks_generate_like_the_unsharded_oracle(name, dtype, shard_mlp):
+def test_two_ranks_generate_like_the_unsharded_oracle(name, dtype, shard_mlp, oneshot):
     import torch.multiprocessing as mp
     from oracle import ops_ref as R
     from oracle.tiny_models import make_prompts, make_weights
@@ -98,7 +105,7 @@ def test_two_ranks_generate_like_the_unsharded_oracle(name, dtype, shard_mlp):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, dtype, shard_mlp, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, dtype, shard_mlp, q, oneshot)) for r in range(2)]
     for p in procs:
         p.start()
     import queue

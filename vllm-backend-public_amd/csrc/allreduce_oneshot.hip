@@ -1,0 +1,248 @@
+// One-shot all-reduce (sum) for the small messages of a tensor-parallel decode step
+// ([tokens, hidden] 16-bit partial sums after o_proj / down_proj: 256 KiB - 1 MiB).
+//
+// Every rank owns a device buffer that its peers map through HIP IPC handles:
+//   slots [2 parities][world ranks][max_bytes]   data, written by the peers (and by the owner)
+//   flags [world ranks][kMaxBlocks]              last round whose data a peer's workgroup delivered
+// A call is one kernel of nblocks workgroups on every rank.  Workgroup b of rank r
+//   1. copies chunk b of its input into slot[parity][r] of EVERY rank's buffer (all links of a
+//      fully connected node carry data at once -- a ring pushes the message through one link
+//      per hop),
+//   2. makes the stores visible (system-scope fence) and writes the round number to
+//      flag[r][b] of every rank,
+//   3. waits until flag[p][b] of its own buffer has reached the round for every p,
+//   4. sums chunk b of the world slots in RANK ORDER in fp32 and writes the rounded result
+//      over its input -- every rank adds the same values in the same order, so the results
+//      are bit-identical across ranks (the lock-step schedulers of the ranks rely on that).
+// Synchronisation is per chunk: no grid-wide barrier, no host round trip, one launch.  The
+// round number lives in device memory (read by every workgroup at its start, advanced by the
+// last workgroup of the call to finish), so a call captured into a HIP graph advances it on
+// every replay.  Slots alternate between two parities: a rank can run
+// at most one call ahead of its slowest peer (it needs that peer's flags of the round), so data
+// of round n+1 never lands in a slot a peer still reads for round n.
+// The buffers are allocated uncached (fine-grained): data written by a peer over xGMI is read
+// from memory, not from a stale line of the reader's L2.
+// Every wait is bounded (kSpinLimitTicks of the constant 100 MHz clock): a peer that never
+// arrives makes the kernel give up, raise the communicator's error word and leave its input
+// untouched -- the grid always drains.
+#include "common.h"
+
+#include <string.h>
+
+namespace mi355 {
+
+constexpr int kArMaxWorld = 8;
+constexpr int kArMaxBlocks = 64;
+constexpr int kArThreads = 256;
+constexpr long long kSpinLimitTicks = 200000000LL;   // 2 s of the 100 MHz wall clock
+
+struct ArPeers {
+  unsigned char* buf[kArMaxWorld];   // every rank's buffer as mapped into THIS process
+};
+
+struct ArComm {
+  int rank, world, device;
+  int64_t max_bytes;
+  unsigned char* local;              // this rank's buffer (hipExtMallocWithFlags, uncached)
+  unsigned char* peer[kArMaxWorld];  // peer[rank] == local
+  bool opened[kArMaxWorld];
+  unsigned* rounds;                  // device words: [0] last completed round, [1] finish ticket, [2] error
+  unsigned* error;                   // = rounds + 2: != 0 after a wait timed out
+  bool connected;
+};
+
+__host__ __device__ inline int64_t ar_flags_offset(int world, int64_t max_bytes) {
+  return 2 * static_cast<int64_t>(world) * max_bytes;
+}
+inline int64_t ar_buffer_bytes(int world, int64_t max_bytes) {
+  return ar_flags_offset(world, max_bytes) + static_cast<int64_t>(world) * kArMaxBlocks * sizeof(unsigned);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
+    uint16_t* __restrict__ data, int64_t count, ArPeers peers, int rank, int world, int64_t max_bytes,
+    unsigned* __restrict__ rounds, unsigned* __restrict__ error) {
+  const int b = blockIdx.x, nb = gridDim.x, tid = threadIdx.x;
+  // the call's round: one more than the last completed call's (nobody advances the word before
+  // every workgroup of this call has finished, hence read it)
+  const unsigned round = __hip_atomic_load(rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  const int parity = round & 1;
+  const int64_t nvec = count >> 3;                    // 16-byte vectors (count % 8 == 0)
+  const int64_t per = (nvec + nb - 1) / nb;
+  const int64_t v0 = b * per, v1 = min(nvec, v0 + per);
+  const int64_t slot_bytes = max_bytes;
+  const int64_t flags_off = ar_flags_offset(world, max_bytes);
+  const uint4* src = reinterpret_cast<const uint4*>(data);
+
+  // 1. deliver this rank's chunk to every rank (own buffer included: the sum below reads all slots alike)
+  for (int p = 0; p < world; ++p) {
+    uint4* dst = reinterpret_cast<uint4*>(peers.buf[p] + (static_cast<int64_t>(parity) * world + rank) * slot_bytes);
+    for (int64_t v = v0 + tid; v < v1; v += kArThreads) dst[v] = src[v];
+  }
+  // 2. stores first, then the flag: release at system scope, by every thread that stored
+  __threadfence_system();
+  __syncthreads();
+  if (tid < world) {
+    unsigned* flag = reinterpret_cast<unsigned*>(peers.buf[tid] + flags_off) + rank * kArMaxBlocks + b;
+    __hip_atomic_store(flag, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // 3. wait for chunk b of every rank (bounded)
+  __shared__ int ok_s;
+  if (tid == 0) ok_s = 1;
+  __syncthreads();
+  if (tid < world) {
+    const unsigned* flag = reinterpret_cast<const unsigned*>(peers.buf[rank] + flags_off) + tid * kArMaxBlocks + b;
+    const long long t0 = wall_clock64();
+    bool ok = true;
+    // rounds are compared modulo 2^32: "reached" = not more than half the range behind
+    while (static_cast<int>(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - round) < 0) {
+      if (wall_clock64() - t0 > kSpinLimitTicks) {
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (!ok) {
+      ok_s = 0;
+      atomicExch(error, 1u + static_cast<unsigned>(tid));     // which peer did not arrive
+    }
+  }
+  __syncthreads();
+  const bool ok_all = ok_s != 0;
+  if (ok_all) {
+    __threadfence_system();                           // acquire for the data loads of every thread
+
+  // 4. sum in rank order, fp32, one rounding
+  const unsigned char* mine = peers.buf[rank] + static_cast<int64_t>(parity) * world * slot_bytes;
+  uint4* out = reinterpret_cast<uint4*>(data);
+  for (int64_t v = v0 + tid; v < v1; v += kArThreads) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int p = 0; p < world; ++p) {
+      float f[8];
+      unpack8<T>(reinterpret_cast<const uint4*>(mine + p * slot_bytes)[v], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
+    out[v] = pack8<T>(acc);
+  }
+  }   // a timed-out wait leaves the input as it was; the host sees the error word
+  // the last workgroup to finish spends the round (a failed call too: the peers' flags stay comparable)
+  __syncthreads();
+  if (tid == 0) {
+    if (__hip_atomic_fetch_add(rounds + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(nb - 1)) {
+      __hip_atomic_store(rounds + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rounds, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+}  // namespace mi355
+
+extern "C" int64_t mi355_allreduce_oneshot_handle_bytes(void) { return static_cast<int64_t>(sizeof(hipIpcMemHandle_t)); }
+
+extern "C" int32_t mi355_allreduce_oneshot_init(void** comm_out, int32_t rank, int32_t world, int64_t max_bytes,
+                                                void* handle_out) {
+  using namespace mi355;
+  const char* name = "mi355_allreduce_oneshot_init";
+  MI355_REQUIRE(comm_out && handle_out, MI355_ERR_INVALID, "%s: null pointer", name);
+  MI355_REQUIRE(world >= 1 && world <= kArMaxWorld && rank >= 0 && rank < world, MI355_ERR_INVALID,
+                "%s: rank %d / world %d out of range (world <= %d)", name, rank, world, kArMaxWorld);
+  MI355_REQUIRE(max_bytes >= 16 && max_bytes % 16 == 0 && max_bytes <= (16 << 20), MI355_ERR_INVALID,
+                "%s: max_bytes %lld must be a multiple of 16 in [16, 16 MiB]", name, (long long)max_bytes);
+  ArComm* c = new ArComm();
+  memset(c, 0, sizeof(*c));
+  c->rank = rank, c->world = world, c->max_bytes = max_bytes;
+  hipError_t e = hipGetDevice(&c->device);
+  const int64_t bytes = ar_buffer_bytes(world, max_bytes);
+  if (e == hipSuccess) e = hipExtMallocWithFlags(reinterpret_cast<void**>(&c->local), bytes, hipDeviceMallocUncached);
+  if (e == hipSuccess) e = hipMemset(c->local, 0, bytes);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->rounds), 4 * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(c->rounds, 0, 4 * sizeof(unsigned));
+  if (e == hipSuccess) e = hipIpcGetMemHandle(static_cast<hipIpcMemHandle_t*>(handle_out), c->local);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    if (c->local) (void)hipFree(c->local);
+    if (c->rounds) (void)hipFree(c->rounds);
+    delete c;
+    return fail(MI355_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
+  }
+  c->error = c->rounds + 2;
+  c->peer[rank] = c->local;
+  *comm_out = c;
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_allreduce_oneshot_connect(void* comm, const void* all_handles) {
+  using namespace mi355;
+  const char* name = "mi355_allreduce_oneshot_connect";
+  MI355_REQUIRE(comm && all_handles, MI355_ERR_INVALID, "%s: null pointer", name);
+  ArComm* c = static_cast<ArComm*>(comm);
+  MI355_REQUIRE(!c->connected, MI355_ERR_INVALID, "%s: already connected", name);
+  const auto* handles = static_cast<const hipIpcMemHandle_t*>(all_handles);
+  for (int p = 0; p < c->world; ++p) {
+    if (p == c->rank) continue;
+    void* ptr = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&ptr, handles[p], hipIpcMemLazyEnablePeerAccess);
+    MI355_REQUIRE(e == hipSuccess && ptr, MI355_ERR_LAUNCH, "%s: cannot map the buffer of rank %d: %s", name, p,
+                  hipGetErrorString(e));
+    c->peer[p] = static_cast<unsigned char*>(ptr);
+    c->opened[p] = true;
+  }
+  c->connected = true;
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_allreduce_oneshot_run(void* comm, void* data, int64_t count, int32_t dtype, void* stream) {
+  using namespace mi355;
+  const char* name = "mi355_allreduce_oneshot_run";
+  MI355_REQUIRE(comm && data, MI355_ERR_INVALID, "%s: null pointer", name);
+  ArComm* c = static_cast<ArComm*>(comm);
+  MI355_REQUIRE(c->connected, MI355_ERR_INVALID, "%s: not connected (exchange the handles first)", name);
+  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED, "%s: dtype %d not supported (bf16/fp16 only)",
+                name, dtype);
+  MI355_REQUIRE(count >= 0 && count % 8 == 0 && count * 2 <= c->max_bytes && aligned16(data), MI355_ERR_INVALID,
+                "%s: count %lld must be a multiple of 8 with count * 2 <= max_bytes %lld, data 16-byte aligned", name,
+                (long long)count, (long long)c->max_bytes);
+  if (count == 0) return MI355_OK;
+  ArPeers peers;
+  for (int p = 0; p < kArMaxWorld; ++p) peers.buf[p] = c->peer[p < c->world ? p : c->rank];
+  // one workgroup per 16 KB, the SAME count on every rank (it only depends on `count`)
+  int nb = static_cast<int>((count * 2 + 16383) / 16384);
+  nb = nb < 1 ? 1 : nb > kArMaxBlocks ? kArMaxBlocks : nb;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == MI355_BF16)
+    hipLaunchKernelGGL((allreduce_oneshot_kernel<BF16>), dim3(nb), dim3(kArThreads), 0, s, static_cast<uint16_t*>(data),
+                       count, peers, c->rank, c->world, c->max_bytes, c->rounds, c->error);
+  else
+    hipLaunchKernelGGL((allreduce_oneshot_kernel<F16>), dim3(nb), dim3(kArThreads), 0, s, static_cast<uint16_t*>(data),
+                       count, peers, c->rank, c->world, c->max_bytes, c->rounds, c->error);
+  return check_launch(name);
+}
+
+extern "C" int32_t mi355_allreduce_oneshot_status(void* comm) {
+  using namespace mi355;
+  const char* name = "mi355_allreduce_oneshot_status";
+  MI355_REQUIRE(comm, MI355_ERR_INVALID, "%s: null pointer", name);
+  ArComm* c = static_cast<ArComm*>(comm);
+  unsigned err = 0;
+  const hipError_t e = hipMemcpy(&err, c->error, sizeof(err), hipMemcpyDeviceToHost);   // waits for the work queued before it
+  MI355_REQUIRE(e == hipSuccess, MI355_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
+  MI355_REQUIRE(err == 0, MI355_ERR_LAUNCH, "%s: rank %d waited 2 s for rank %u, which never delivered its chunk", name, c->rank,
+                err - 1);
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_allreduce_oneshot_destroy(void* comm) {
+  using namespace mi355;
+  if (!comm) return MI355_OK;
+  ArComm* c = static_cast<ArComm*>(comm);
+  (void)hipDeviceSynchronize();
+  for (int p = 0; p < c->world; ++p)
+    if (c->opened[p]) (void)hipIpcCloseMemHandle(c->peer[p]);
+  if (c->local) (void)hipFree(c->local);
+  if (c->rounds) (void)hipFree(c->rounds);
+  delete c;
+  return MI355_OK;
+}

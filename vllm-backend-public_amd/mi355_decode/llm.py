@@ -117,6 +117,13 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
     runner = ModelRunner(cfg, weights, dtype, device, num_blocks, args.max_num_seqs, max_model_len,
                          tp_rank=rank, tp_size=tp, tp_group=group, use_graphs=graphs,
                          decode_splits=decode_splits, weight_fp8=(args.quantization or "").lower() == "fp8")
+    if tp > 1 and os.environ.get("MI355_ONESHOT_ALLREDUCE", "0") == "1":
+        # opt-in: the hand-written one-shot all-reduce for decode-sized messages (run with two ranks on
+        # one GPU so far, not across xGMI links); larger messages stay on the process group
+        from .collectives import OneShotAllReduce
+        rows = max(args.max_num_seqs, 16)
+        runner.oneshot = OneShotAllReduce(group, max_bytes=min(max(1 << 20, rows * cfg.hidden_size * 2), 16 << 20))
+        log.info("rank %d: one-shot all-reduce for messages up to %d bytes", rank, runner.oneshot.max_bytes)
     if os.environ.get("MI355_LAZY_TUNE", "0") != "1":
         runner.warm_up()                              # every rank, same order: the choices are broadcast
     log.info("tensor-parallel rank %d of %d on %s: %d layers, MLP %s, lm_head %s, %d KV pages, HIP graphs %s",

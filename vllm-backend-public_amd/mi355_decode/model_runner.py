@@ -100,6 +100,8 @@ class ModelRunner:
         self.capture_failures = 0                     # exported on /metrics and in the bench line
         self.tune_failures = 0
         self._device_collectives = None               # decided at the first collective (see _collective)
+        self.oneshot = None                           # collectives.OneShotAllReduce, set by build_engine (opt-in)
+        self.oneshot_calls = 0
         self.decode_splits = decode_splits
         self.weight_fp8 = bool(weight_fp8)
 
@@ -560,8 +562,15 @@ class ModelRunner:
         return max(1, min(want, by_len, self._max_splits))
 
     def _allreduce(self, t: torch.Tensor) -> None:
+        """Sum of the ranks' partial results, in place.  Decode-sized 16-bit messages take the one-shot
+        kernel over peer-mapped buffers when the engine was built with one (every rank adds in rank
+        order: bit-identical results); everything else the process group's all-reduce."""
         if self.tp_size > 1:
-            self._collective(lambda c: torch.distributed.all_reduce(c, group=self.tp_group), t)
+            if self.oneshot is not None and self.oneshot.fits(t):
+                self.oneshot.run(t)
+                self.oneshot_calls += 1
+            else:
+                self._collective(lambda c: torch.distributed.all_reduce(c, group=self.tp_group), t)
 
     def _layers(self, n: int, resid, x, qkv, attn, o, gu, act, dn, attend) -> torch.Tensor:
         """Runs all decoder layers over n packed tokens held in `resid`.  Returns the
@@ -728,6 +737,10 @@ class ModelRunner:
         """Waits for the step launched on `stage`; returns its sampled ids as a list (and, with
         `logprobs` >= 0 as at launch, the per-row log-probabilities from _unpack_logprobs)."""
         self.done[stage].synchronize()
+        if self.oneshot is not None:
+            self._finished = getattr(self, "_finished", 0) + 1
+            if self._finished % 64 == 0:
+                self.oneshot.check()                  # a peer that never arrived: raise instead of serving garbage
         toks = self.h_nexts[stage][:batch].tolist()
         if logprobs < 0:
             return toks
