@@ -204,6 +204,111 @@ def time_kernels(engine, batch, ctx_len):
     return out
 
 
+def cpu_baseline_twin(cfg, batch, ctx_len, sample_layers=2, steps=3):
+    """One decode step built from the CPU twin of the operator ABI (libmi355_decode_cpu.so: the same
+    entry points as the GPU library with host pointers, OpenMP) timed on this host: `batch`
+    sequences at context `ctx_len` through `sample_layers` real-shape layers plus the lm_head and
+    the greedy pick, scaled to the model's layer count.  Synthetic bf16 weights (finite, small,
+    random signs: the arithmetic does not depend on the values)."""
+    import ctypes
+
+    import numpy as np
+    lib = ctypes.CDLL(os.path.join(ROOT, "vllm-backend-public_amd", "mi355_decode", "libmi355_decode_cpu.so"))
+    P, I32, I64, F = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+    sig = {"mi355_cpu_rms_norm": [P, P, P, I64, I32, I64, I64, F, I32],
+           "mi355_cpu_fused_add_rms_norm": [P, P, P, P, I64, I32, I64, I64, I64, F, I32],
+           "mi355_cpu_rope_kv_write": [P, I64, P, P, I32, P, P, P, I32, I64, I32, I32, I32, I32],
+           "mi355_cpu_paged_attn_decode": [P, P, I64, P, P, I32, P, I32, P, I32, I32, I32, I32, F, I32],
+           "mi355_cpu_silu_and_mul": [P, P, I64, I64, I32, I32],
+           "mi355_cpu_argmax": [P, P, I64, I32, I32, I32],
+           "mi355_cpu_linear": [P, I64, P, I64, P, P, I32, I32, I32, I32]}
+    for name, args in sig.items():
+        getattr(lib, name).restype, getattr(lib, name).argtypes = I32, args
+    lib.mi355_cpu_last_error.restype = ctypes.c_char_p
+    H, Fi, V, d = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.head_dim
+    nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    qw = (nh + 2 * nkv) * d
+    rng = np.random.Generator(np.random.PCG64(0))
+
+    def buf(*shape):                       # 16-byte aligned uint16 words
+        n = int(np.prod(shape))
+        raw = np.empty(n * 2 + 16, np.uint8)
+        off = (-raw.ctypes.data) % 16
+        return raw[off:off + n * 2].view(np.uint16).reshape(shape)
+
+    def mat(*shape):                       # bf16 words of magnitude 2^-7 .. 2^-6, random sign and mantissa
+        a = buf(*shape)
+        a[...] = (rng.integers(0, 1 << 16, size=shape, dtype=np.uint16) & np.uint16(0x807F)) | np.uint16(0x3C00)
+        return a
+
+    def ones(n):
+        a = buf(n)
+        a[...] = 0x3F80
+        return a
+
+    layers = [dict(qkv=mat(qw, H), o=mat(H, nh * d), gu=mat(2 * Fi, H), down=mat(H, Fi), n1=ones(H), n2=ones(H))
+              for _ in range(sample_layers)]
+    embed_rows, lm_head, final_norm = mat(batch, H), mat(V, H), ones(H)
+    max_pos = ctx_len + steps + 8
+    blocks_per_seq = (max_pos + 15) // 16
+    nblk = batch * blocks_per_seq
+    kc = [mat(nblk, nkv, 16, d) for _ in range(sample_layers)]
+    vc = [mat(nblk, nkv, d, 16) for _ in range(sample_layers)]
+    cos_sin = mat(max_pos, d)
+    bt = np.arange(nblk, dtype=np.int32).reshape(batch, blocks_per_seq)
+    resid, x, qkv, attn, o, gu, act, dn = (buf(batch, w) for w in (H, H, qw, nh * d, H, 2 * Fi, Fi, H))
+    logits, ids = buf(batch, V), np.zeros(batch, np.int64)
+    ptr = lambda a: a.ctypes.data   # noqa: E731
+
+    def ok(rc):
+        if rc != 0:
+            raise RuntimeError(lib.mi355_cpu_last_error().decode())
+
+    def step(k, with_head):
+        pos = np.full(batch, ctx_len - 1 + k, dtype=np.int64)
+        slots = bt[np.arange(batch), pos // 16].astype(np.int64) * 16 + pos % 16
+        ctx = (pos + 1).astype(np.int32)
+        t0 = time.perf_counter()
+        resid[...] = embed_rows
+        for i, lw in enumerate(layers):
+            if i == 0:
+                ok(lib.mi355_cpu_rms_norm(ptr(x), ptr(resid), ptr(lw["n1"]), batch, H, H, H, cfg.rms_norm_eps, 0))
+            else:
+                ok(lib.mi355_cpu_fused_add_rms_norm(ptr(x), ptr(dn), ptr(resid), ptr(lw["n1"]), batch, H, H, H, H,
+                                                    cfg.rms_norm_eps, 0))
+            ok(lib.mi355_cpu_linear(ptr(qkv), qw, ptr(x), H, ptr(lw["qkv"]), None, batch, qw, H, 0))
+            ok(lib.mi355_cpu_rope_kv_write(ptr(qkv), qw, ptr(pos), ptr(cos_sin), max_pos, ptr(slots), ptr(kc[i]), ptr(vc[i]),
+                                           nblk, batch, nh, nkv, d, 0))
+            ok(lib.mi355_cpu_paged_attn_decode(ptr(attn), ptr(qkv), qw, ptr(kc[i]), ptr(vc[i]), nblk, ptr(bt), blocks_per_seq,
+                                               ptr(ctx), batch, nh, nkv, d, d ** -0.5, 0))
+            ok(lib.mi355_cpu_linear(ptr(o), H, ptr(attn), nh * d, ptr(lw["o"]), None, batch, H, nh * d, 0))
+            ok(lib.mi355_cpu_fused_add_rms_norm(ptr(x), ptr(o), ptr(resid), ptr(lw["n2"]), batch, H, H, H, H, cfg.rms_norm_eps, 0))
+            ok(lib.mi355_cpu_linear(ptr(gu), 2 * Fi, ptr(x), H, ptr(lw["gu"]), None, batch, 2 * Fi, H, 0))
+            ok(lib.mi355_cpu_silu_and_mul(ptr(act), ptr(gu), 2 * Fi, batch, Fi, 0))
+            ok(lib.mi355_cpu_linear(ptr(dn), H, ptr(act), Fi, ptr(lw["down"]), None, batch, H, Fi, 0))
+        t_layers = time.perf_counter() - t0
+        if with_head:
+            ok(lib.mi355_cpu_fused_add_rms_norm(ptr(x), ptr(dn), ptr(resid), ptr(final_norm), batch, H, H, H, H,
+                                                cfg.rms_norm_eps, 0))
+            ok(lib.mi355_cpu_linear(ptr(logits), V, ptr(x), H, ptr(lm_head), None, batch, V, H, 0))
+            ok(lib.mi355_cpu_argmax(ptr(ids), ptr(logits), V, batch, V, 0))
+        return t_layers, time.perf_counter() - t0
+
+    step(0, True)                                              # warm the threads and the page cache
+    runs = [step(1 + k, True) for k in range(steps)]
+    t_layers = min(r[0] for r in runs)
+    t_head = min(r[1] - r[0] for r in runs)
+    per_layer = t_layers / sample_layers
+    step_s = per_layer * cfg.num_hidden_layers + t_head
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    return {"value": round(batch / step_s, 2), "unit": "tok/s", "cores": threads, "kind": "port",
+            "sample": (f"CPU twin of the operator ABI (libmi355_decode_cpu.so, C++/OpenMP), {steps} decode steps of batch {batch} at "
+                       f"context {ctx_len} through {sample_layers} of {cfg.num_hidden_layers} real-shape layers + lm_head + argmax; "
+                       f"per-layer time {per_layer * 1e3:.0f} ms x {cfg.num_hidden_layers} + head {t_head * 1e3:.0f} ms = "
+                       f"{step_s:.2f} s per step"),
+            "stock_vllm_cpu": "unavailable offline (vllm is not installed; nothing can be fetched)"}
+
+
 def cpu_baseline(cfg, batch, ctx_len, sample_layers=2, steps=2):
     """The numpy oracle (oracle/model_ref.py) timed on this host: one decode step of
     `batch` sequences at context `ctx_len` through `sample_layers` real-shape layers
@@ -554,9 +659,13 @@ def main():
     if rank == 0:
         if not a.no_cpu_baseline and a.gpus == 1:
             try:
-                result["cpu_baseline"] = cpu_baseline(cfg, a.batch_per_gpu, int(mean_ctx))
-            except Exception as exc:                      # never lose the GPU measurement
-                result["cpu_baseline"] = {"value": None, "error": repr(exc)}
+                result["cpu_baseline"] = cpu_baseline_twin(cfg, a.batch_per_gpu, int(mean_ctx))
+            except Exception as exc:                      # the twin is missing or failed: the numpy oracle instead
+                try:
+                    result["cpu_baseline"] = cpu_baseline(cfg, a.batch_per_gpu, int(mean_ctx))
+                    result["cpu_baseline"]["twin_error"] = repr(exc)
+                except Exception as exc2:                 # never lose the GPU measurement
+                    result["cpu_baseline"] = {"value": None, "error": repr(exc2)}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
