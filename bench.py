@@ -458,7 +458,7 @@ def pmc_traffic(tiled):
     """(HBM bytes per launch of the gate/up GEMM, source) from the committed rocprofv3
     PMC summary of this workload, or (None, None)."""
     import re
-    name = "r01_p_pmc_traffic.json" if tiled else "r01_b_pmc_traffic.json"
+    name = "r02_pmc_traffic.json" if tiled else "r01_b_pmc_traffic.json"
     # the gate/up GEMM is the instantiation with the SwiGLU epilogue (5th template argument == 1)
     pat = re.compile(r"linear_tiled_kernel<\w+, \d+, \d+, \d+, 1[,>]" if tiled else r"gemm_gate_up")
     try:
