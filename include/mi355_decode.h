@@ -292,7 +292,11 @@ int32_t mi355_argmax_key_to_index(int64_t* out_ids, const int64_t* keys,
  * number from a counter hash of (seeds[b], steps[b]) picks the token by inverse
  * CDF.  All of it is fixed-order fp32 arithmetic: a (logits, parameters, seed,
  * step) tuple always yields the same token, on any launch.  Rows with
- * temperature[b] <= 0 get the greedy token (mi355_argmax semantics).  Serves
+ * temperature[b] <= 0 get the greedy token (mi355_argmax semantics); a row that
+ * holds a NaN yields the index of its first NaN from either.  NOTE the candidate
+ * set never exceeds the 1024 most likely tokens: top_k <= 0 ("disabled") samples
+ * from those 1024, not from the whole vocabulary (the tail beyond them carries a
+ * negligible mass for a trained model; the server rejects top_k > 1024).  Serves
  * temperature/top_k/top_p/seed of POST /v1/completions
  * (benchmark-deployer/docs/deployment/post_run.md:46).
  */

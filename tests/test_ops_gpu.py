@@ -492,7 +492,7 @@ def test_sample_topk_topp(ops, ldt, B, V):
     lg[0, 5] = -0.0
     if B > 2:
         lg[1, : V // 2] = lg[1, 0]                          # a huge tie that straddles the top-k threshold
-        lg[2, 7] = np.nan                                   # NaN is never a candidate
+        lg[2, 7] = np.nan                                   # a NaN sorts on top: the row yields its index, like argmax
     temperature = rng.choice([0.0, 0.3, 0.7, 1.0, 1.5], B).astype(np.float32)
     temperature[:3] = [1.0, 0.8, 1.2][: min(3, B)]
     top_k = rng.choice([-1, 1, 2, 5, 40, 1024, 5000], B).astype(np.int32)
@@ -506,6 +506,8 @@ def test_sample_topk_topp(ops, ldt, B, V):
         out = ops.sample(lgd, torch.from_numpy(temperature).cuda(), torch.from_numpy(top_k).cuda(),
                          torch.from_numpy(top_p).cuda(), torch.from_numpy(seeds).cuda(), torch.from_numpy(steps).cuda())
         np.testing.assert_array_equal(out.cpu().numpy(), ref)
+        if B > 2:
+            assert out[2].item() == 7
 
 
 def test_sample_distribution(ops):

@@ -138,6 +138,43 @@ def test_sampling_parameters_are_accepted():
     th.shutdown()
 
 
+def test_top_k_beyond_the_candidate_set_is_rejected():
+    th, c, _, _ = make()
+    th.ready.wait(10)
+    r = c.post("/v1/completions", json={"prompt": [1, 2], "max_tokens": 3, "temperature": 0.8, "top_k": 5000})
+    assert r.status_code == 400 and "1024" in r.json()["error"]["message"]
+    th.shutdown()
+
+
+def test_chat_completions_share_the_generation_path():
+    th, c, _, tok = make()
+    th.ready.wait(10)
+    msgs = [{"role": "system", "content": "be brief"}, {"role": "user", "content": [{"type": "text", "text": "hi"}]}]
+    prompt = "<|system|>\nbe brief\n\n<|user|>\nhi\n\n<|assistant|>\n"
+    r = c.post("/v1/chat/completions", json={"model": "test-model", "messages": msgs, "max_tokens": 5, "temperature": 0})
+    assert r.status_code == 200, r.text
+    body = r.json()
+    assert body["object"] == "chat.completion" and body["id"].startswith("chatcmpl-")
+    ch = body["choices"][0]
+    assert ch["message"] == {"role": "assistant", "content": tok.decode(reference(tok.encode(prompt), 5))}
+    assert ch["finish_reason"] == "length" and body["usage"]["prompt_tokens"] == len(tok.encode(prompt))
+    # the same text through the plain route
+    r2 = c.post("/v1/completions", json={"prompt": prompt, "max_tokens": 5, "temperature": 0})
+    assert r2.json()["choices"][0]["text"] == ch["message"]["content"]
+    # streaming: a role first, content deltas, a finish reason, [DONE]
+    with c.stream("POST", "/v1/chat/completions", json={"messages": msgs, "max_tokens": 4, "temperature": 0, "stream": True}) as r:
+        lines = [ln for ln in r.iter_lines() if ln.startswith("data: ")]
+    assert lines[-1] == "data: [DONE]"
+    chunks = [json.loads(ln[6:]) for ln in lines[:-1]]
+    assert all(ch_["object"] == "chat.completion.chunk" for ch_ in chunks)
+    assert chunks[0]["choices"][0]["delta"].get("role") == "assistant"
+    assert "".join(ch_["choices"][0]["delta"].get("content", "") for ch_ in chunks) == tok.decode(reference(tok.encode(prompt), 4))
+    assert chunks[-1]["choices"][0]["finish_reason"] == "length"
+    assert c.post("/v1/chat/completions", json={"messages": []}).status_code == 400
+    assert c.post("/v1/chat/completions", json={"messages": [{"content": "x"}]}).status_code == 400
+    th.shutdown()
+
+
 def test_many_concurrent_requests_and_health_stays_fast():
     th, c, _, tok = make()
     th.ready.wait(10)

@@ -171,8 +171,10 @@ __global__ void argmax_key_to_index_kernel(int64_t* __restrict__ out, const int6
 constexpr int kSampleThreads = 1024;
 constexpr int kSampleKMax = 1024;
 
+// NaN sorts on top, as in argmax_key: a row that holds a NaN yields the index of its first NaN
+// from greedy and from random sampling alike
 __device__ __forceinline__ uint32_t sample_key(float v) {
-  if (v != v) return 0u;
+  if (v != v) return 0xFFFFFFFFu;
   uint32_t u = (v == 0.0f) ? 0u : __float_as_uint(v);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
@@ -345,7 +347,9 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
     csum[tid] = exp_det(z);
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid == 0 && static_cast<uint32_t>(comp[0] >> 32) == 0xFFFFFFFFu) {   // a NaN logit: its index, like argmax
+    out[row] = static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(comp[0] & 0xFFFFFFFFull));
+  } else if (tid == 0) {
     float acc = 0.0f;
     for (int i = 0; i < k; ++i) {
       acc = acc + csum[i];

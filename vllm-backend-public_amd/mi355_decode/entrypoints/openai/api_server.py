@@ -56,6 +56,29 @@ def normalise_prompts(prompt, tokenizer, vocab_size: int) -> List[List[int]]:
     raise ValueError("prompt must be a string, a list of strings, a list of token ids or a list of token-id lists")
 
 
+def render_chat(messages, tokenizer) -> str:
+    """messages [{role, content}] -> one prompt string ending where the assistant's answer begins.
+    The model directory's own template is used when the tokenizer carries one (`chat_template`, a
+    Jinja string from tokenizer_config.json); otherwise a plain transcript: `<|role|>` line,
+    content, blank line."""
+    for m in messages:
+        if not isinstance(m, dict) or not isinstance(m.get("role"), str):
+            raise ValueError("every message needs a role")
+        c = m.get("content")
+        if isinstance(c, list):                           # content parts: the text ones, concatenated
+            m["content"] = "".join(p.get("text", "") for p in c if isinstance(p, dict) and p.get("type") == "text")
+        elif not isinstance(c, str):
+            raise ValueError("message content must be a string or a list of text parts")
+    template = getattr(tokenizer, "chat_template", None)
+    if template:
+        import jinja2
+        env = jinja2.Environment(trim_blocks=True, lstrip_blocks=True)
+        return env.from_string(template).render(messages=messages, add_generation_prompt=True,
+                                                bos_token=getattr(tokenizer, "bos_token", "") or "",
+                                                eos_token=getattr(tokenizer, "eos_token", "") or "")
+    return "".join(f"<|{m['role']}|>\n{m['content']}\n\n" for m in messages) + "<|assistant|>\n"
+
+
 def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int, max_model_len: int):
     from ...sampling_params import SamplingParams
     from ...tokenizer import IncrementalDetokenizer
@@ -116,6 +139,16 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
 
     @app.post("/v1/completions")
     async def completions(request: Request):
+        return await serve(request, chat=False)
+
+    @app.post("/v1/chat/completions")
+    async def chat_completions(request: Request):
+        """Chat form of the same generation path: the messages are rendered to one prompt (the model
+        directory's chat template when it has one, a plain role-tagged transcript otherwise) and the
+        answer comes back as an assistant message (`chat.completion` / `chat.completion.chunk`)."""
+        return await serve(request, chat=True)
+
+    async def serve(request: Request, chat: bool):
         bad = not_ready()
         if bad is not None:
             return bad
@@ -123,6 +156,21 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
             body = await request.json()
         except Exception:
             return _error(400, "request body is not valid JSON")
+        if chat:
+            if not isinstance(body, dict) or not isinstance(body.get("messages"), list) or not body["messages"]:
+                return _error(400, "missing field: messages")
+            try:
+                body = dict(body, prompt=render_chat(body["messages"], tokenizer))
+            except (ValueError, TypeError, KeyError) as exc:
+                return _error(400, f"cannot render the messages: {exc}")
+            if body.get("max_tokens") is None:
+                body["max_tokens"] = body.get("max_completion_tokens") or max(
+                    1, max_model_len - len(tokenizer.encode(body["prompt"])) - 1)
+            body.pop("echo", None)
+            if body.get("logprobs") is True:              # chat form: a boolean + top_logprobs
+                body["logprobs"] = int(body.get("top_logprobs") or 0)
+            elif body.get("logprobs") is False:
+                body["logprobs"] = None
         if not isinstance(body, dict) or "prompt" not in body:
             return _error(400, "missing field: prompt")
         model = body.get("model") or served_model_name
@@ -147,6 +195,9 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
                 stop_token_ids=list(body.get("stop_token_ids") or []),
                 ignore_eos=bool(body.get("ignore_eos", False)), logprobs=want_lp,
                 prompt_logprobs=prompt_lp)
+            if params.top_k > 1024:
+                raise ValueError("top_k above 1024 is not supported: sampling draws from at most the 1024 most likely "
+                                 "tokens (top_k <= 0 means those 1024)")
             for p in prompts:
                 if len(p) + 1 > max_model_len:
                     raise ValueError(f"This model's maximum context length is {max_model_len} tokens; the prompt has "
@@ -160,7 +211,7 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
 
         stream = bool(body.get("stream", False))
         echo = bool(body.get("echo", False))
-        cmpl_id = "cmpl-" + uuid.uuid4().hex
+        cmpl_id = ("chatcmpl-" if chat else "cmpl-") + uuid.uuid4().hex
         loop = asyncio.get_running_loop()
         q: asyncio.Queue = asyncio.Queue()
         rids = [f"{cmpl_id}-{i}" for i in range(len(prompts))]
@@ -240,15 +291,23 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
         usage = lambda: {"prompt_tokens": sum(len(p) for p in prompts), "completion_tokens": sum(n_out),  # noqa: E731
                          "total_tokens": sum(len(p) for p in prompts) + sum(n_out)}
 
+        started = [False] * len(prompts)
         if stream:
             async def sse():
                 try:
                     async for i, delta, reason, step_lp in events():
                         # one event per generated token, as the engine this replaces streams them: the
                         # text may be empty while the detokenizer holds back an unfinished UTF-8 sequence
-                        chunk = {"id": cmpl_id, "object": "text_completion", "created": int(time.time()),
-                                 "model": served_model_name,
-                                 "choices": [{"index": i, "text": delta, "logprobs": step_lp, "finish_reason": reason}]}
+                        if chat:
+                            d = {"content": delta}
+                            if not started[i]:
+                                started[i] = True
+                                d["role"] = "assistant"
+                            choice = {"index": i, "delta": d, "logprobs": step_lp, "finish_reason": reason}
+                        else:
+                            choice = {"index": i, "text": delta, "logprobs": step_lp, "finish_reason": reason}
+                        chunk = {"id": cmpl_id, "object": "chat.completion.chunk" if chat else "text_completion",
+                                 "created": int(time.time()), "model": served_model_name, "choices": [choice]}
                         yield f"data: {json.dumps(chunk)}\n\n"
                     yield "data: [DONE]\n\n"
                 except asyncio.CancelledError:
@@ -269,11 +328,14 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
             return _error(400, str(exc))
         except Exception as exc:
             return _error(500, f"engine error: {exc!r}", "internal_error")
-        return JSONResponse({"id": cmpl_id, "object": "text_completion", "created": int(time.time()),
-                             "model": served_model_name,
-                             "choices": [{"index": i, "text": texts[i], "logprobs": lp_objs[i], "finish_reason": reasons[i]}
-                                         for i in range(len(prompts))],
-                             "usage": usage()})
+        if chat:
+            choices = [{"index": i, "message": {"role": "assistant", "content": texts[i]}, "logprobs": lp_objs[i],
+                        "finish_reason": reasons[i]} for i in range(len(prompts))]
+        else:
+            choices = [{"index": i, "text": texts[i], "logprobs": lp_objs[i], "finish_reason": reasons[i]}
+                       for i in range(len(prompts))]
+        return JSONResponse({"id": cmpl_id, "object": "chat.completion" if chat else "text_completion",
+                             "created": int(time.time()), "model": served_model_name, "choices": choices, "usage": usage()})
 
     return app
 

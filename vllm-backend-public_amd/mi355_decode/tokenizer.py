@@ -48,7 +48,17 @@ class HFTokenizer:
 def load_tokenizer(model: str, vocab_size: int):
     path = os.path.join(model, "tokenizer.json")
     if os.path.isfile(path):
-        return HFTokenizer(path)
+        tk = HFTokenizer(path)
+        cfg = os.path.join(model, "tokenizer_config.json")
+        if os.path.isfile(cfg):                           # the chat template and the special-token strings it may name
+            import json
+            with open(cfg) as f:
+                meta = json.load(f)
+            tk.chat_template = meta.get("chat_template") if isinstance(meta.get("chat_template"), str) else None
+            for key in ("bos_token", "eos_token"):
+                v = meta.get(key)
+                setattr(tk, key, v.get("content") if isinstance(v, dict) else v)
+        return tk
     return ByteTokenizer(vocab_size)
 
 
