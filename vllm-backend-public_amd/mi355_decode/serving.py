@@ -51,6 +51,9 @@ class EngineThread:
         self.control_group, self.rank = control_group, rank
         self.thread = threading.Thread(target=self._run, name="mi355-engine", daemon=True)
         self.sink_loops = {}                 # request_id -> asyncio loop its sink must run on (or absent)
+        import os
+        self.admission_window = float(os.environ.get("MI355_ADMISSION_WINDOW_MS", "1.0")) * 1e-3
+        self.admission_cap = float(os.environ.get("MI355_ADMISSION_CAP_MS", "20.0")) * 1e-3
         self.steps = 0
         self.tokens_out = 0
         self.started = time.time()
@@ -88,6 +91,21 @@ class EngineThread:
                 msgs.append(self.inbox.get_nowait())
         except queue.Empty:
             pass
+        # Admission window: requests of one client burst arrive a fraction of a millisecond apart;
+        # prefilling each as it lands would stagger the batch over several prefill steps.  While
+        # new requests keep arriving within `admission_window` of each other (and for at most
+        # `admission_cap` in all) the engine waits for the rest of the burst before it schedules.
+        # (The engine this replaces has the same knob: its scheduler delay factor.)
+        if self.admission_window > 0 and any(isinstance(m, _Add) for m in msgs):
+            t_end = time.perf_counter() + self.admission_cap
+            while time.perf_counter() < t_end:
+                try:
+                    m = self.inbox.get(timeout=self.admission_window)
+                except queue.Empty:
+                    break
+                msgs.append(m)
+                if m is None:
+                    break
         return msgs
 
     def _exchange(self, msgs: list) -> list:
