@@ -200,7 +200,10 @@ def time_kernels(engine, batch, ctx_len):
                                                   num_splits=splits, workspace=r.attn_ws, out=attn),
             kv_bytes + rope_bytes)
     out["paged_attn_decode_fused"]["splits"] = splits
-    out["argmax"] = timed(lambda i: ops.argmax(r.logits[:b], out=r.next_ids[:b]), b * r.Vl * es)
+    if b <= r.keys.numel():      # the many-workgroup form the decode step runs
+        out["argmax"] = timed(lambda i: ops.argmax_chunked(r.logits[:b], r.keys, r.next_ids[:b], r.ids[:b]), b * r.Vl * es)
+    else:
+        out["argmax"] = timed(lambda i: ops.argmax(r.logits[:b], out=r.next_ids[:b]), b * r.Vl * es)
     return out
 
 
