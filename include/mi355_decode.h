@@ -63,6 +63,28 @@ const char* mi355_last_error(void);
 const char* mi355_target_arch(void);
 
 /*
+ * Bounds-checking build (no counterpart in the reference: a debugging aid of this library).
+ * libmi355_decode_bounds.so is the same sources compiled with -DMI355_BOUNDS (`make bounds`):
+ * every global-memory access of every kernel is first compared with the device allocation its
+ * base pointer lies in; an access that leaves it is skipped (a load yields zeros) and the first
+ * one is recorded, so a faulty index is named instead of faulting the GPU.  Many times slower.
+ *   mi355_bounds_enabled      1 in that build, 0 in the library as shipped (where the other two
+ *                             return MI355_ERR_UNSUPPORTED).
+ *   mi355_bounds_set_ranges   the live device allocations as `count` (<= 4096) pairs {lo, hi} of
+ *                             byte addresses, [lo, hi), sorted and disjoint; count 0 switches the
+ *                             checks off (every access passes).  Synchronous; not during capture.
+ *   mi355_bounds_report       out[0..5]: out[0] = refused accesses since the last report; of the
+ *                             first one out[1] = source line, out[2] = base, out[3] = address,
+ *                             out[4] = size, `file` (if not null) = its source file; out[5] =
+ *                             accesses whose base lies in no range of the list (memory allocated
+ *                             after the list was set: performed, only counted).  Clears the
+ *                             record.  The caller synchronises the streams first.
+ */
+int32_t mi355_bounds_enabled(void);
+int32_t mi355_bounds_set_ranges(const uint64_t* lo_hi, int32_t count);
+int32_t mi355_bounds_report(uint64_t* out, char* file, int32_t file_len);
+
+/*
  * RMSNorm:  out = round(round(x * rsqrt(mean(x^2) + eps)) * weight), fp32
  * reduction.  x, out [num_tokens, hidden] with the given row strides; weight
  * [hidden].  Replaces the engine's rms_norm (input_layernorm / final norm of the

@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stddef.h>
 
 #include "mi355_decode.h"
 
@@ -118,6 +119,106 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+
+// ---- global-memory accesses of the kernels ----------------------------------
+// MI355_LD(V, base, p)        load a V from p
+// MI355_LDNT(V, base, p)      the same, non-temporal
+// MI355_ST(V, base, p, v)     store v to p
+// MI355_OK_AT(base, p, bytes) guard of an access of another kind (an atomic): true = go ahead
+// `base` is the kernel argument (the buffer) the address was computed from.  In the library as
+// shipped these are the plain accesses and `base` is not looked at.  Built with -DMI355_BOUNDS
+// (make bounds -> libmi355_decode_bounds.so, a debugging aid, many times slower) every access is
+// first compared with the allocation its base pointer lies in: the host hands the library the
+// list of live device allocations (mi355_bounds_set_ranges), an access that leaves the allocation
+// of its base is NOT performed (a load yields zeros), and the first such access -- source line,
+// base, address, size -- is kept for mi355_bounds_report.  Nothing faults, so one run names the
+// access instead of killing the process.  Before any list is set every access passes; an access
+// whose base the list does not hold (memory allocated after the list was set) is performed and
+// counted.
+#ifdef MI355_BOUNDS
+struct BoundsRange {
+  uint64_t lo, hi;            // [lo, hi)
+};
+constexpr unsigned kBoundsMaxRanges = 4096;
+struct BoundsFirst {
+  unsigned hits, line;        // accesses refused since the last report; line of the first one
+  uint64_t base, addr, bytes;
+  unsigned long long unknown; // accesses whose base lies in no range of the list (memory allocated
+                              // after the list was set): performed, only counted
+};
+struct BoundsState {
+  unsigned count, pad;        // ranges in use: sorted by lo, disjoint
+  BoundsFirst first;
+  BoundsRange r[kBoundsMaxRanges];
+};
+// one copy per translation unit (the library is not built with relocatable device code); every
+// unit registers the two host functions below, and the entry points in abi.hip walk the list
+static __device__ BoundsState g_bounds;
+
+struct BoundsUnit {
+  const char* file;
+  hipError_t (*upload)(const BoundsRange* r, unsigned count);
+  hipError_t (*collect)(BoundsFirst* out);        // reads and clears
+};
+void bounds_register_unit(const BoundsUnit& u);    // abi.hip
+
+static hipError_t bounds_upload(const BoundsRange* r, unsigned count) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_bounds), r, sizeof(BoundsRange) * count, offsetof(BoundsState, r));
+  if (e != hipSuccess) return e;
+  const unsigned head[2] = {count, 0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_bounds), head, sizeof(head), 0);
+}
+static hipError_t bounds_collect(BoundsFirst* out) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bounds), sizeof(BoundsFirst), offsetof(BoundsState, first));
+  if (e != hipSuccess) return e;
+  const BoundsFirst zero = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_bounds), &zero, sizeof(zero), offsetof(BoundsState, first));
+}
+static const struct BoundsAuto {
+  BoundsAuto() { bounds_register_unit(BoundsUnit{__BASE_FILE__, bounds_upload, bounds_collect}); }
+} g_bounds_auto;
+
+__device__ __noinline__ bool bounds_ok(const void* base, const void* p, unsigned bytes, unsigned line) {
+  const unsigned n = g_bounds.count;
+  if (n == 0) return true;
+  const uint64_t b = reinterpret_cast<uint64_t>(base), a = reinterpret_cast<uint64_t>(p);
+  unsigned lo = 0, hi = n;                          // first range whose end lies beyond the base
+  while (lo < hi) {
+    const unsigned mid = (lo + hi) >> 1;
+    if (g_bounds.r[mid].hi <= b) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= n || g_bounds.r[lo].lo > b) {           // a base the list does not know
+    atomicAdd(&g_bounds.first.unknown, 1ull);
+    return true;
+  }
+  if (a >= g_bounds.r[lo].lo && a + bytes <= g_bounds.r[lo].hi) return true;
+  if (atomicAdd(&g_bounds.first.hits, 1u) == 0u) {
+    g_bounds.first.line = line;
+    g_bounds.first.base = b;
+    g_bounds.first.addr = a;
+    g_bounds.first.bytes = bytes;
+  }
+  return false;
+}
+template <typename V>
+__device__ __forceinline__ V bounds_load(const void* base, const void* p, unsigned line) {
+  if (!bounds_ok(base, p, sizeof(V), line)) return V{};
+  return *reinterpret_cast<const V*>(p);
+}
+template <typename V, typename W>
+__device__ __forceinline__ void bounds_store(const void* base, void* p, const W& v, unsigned line) {
+  if (bounds_ok(base, p, sizeof(V), line)) *reinterpret_cast<V*>(p) = v;
+}
+#define MI355_LD(V, base, p) (::mi355::bounds_load<V>((base), (p), __LINE__))
+#define MI355_LDNT(V, base, p) (::mi355::bounds_load<V>((base), (p), __LINE__))
+#define MI355_ST(V, base, p, v) (::mi355::bounds_store<V>((base), (p), (v), __LINE__))
+#define MI355_OK_AT(base, p, bytes) (::mi355::bounds_ok((base), (p), (bytes), __LINE__))
+#else
+#define MI355_LD(V, base, p) (*reinterpret_cast<const V*>(p))
+#define MI355_LDNT(V, base, p) (__builtin_nontemporal_load(reinterpret_cast<const V*>(p)))
+#define MI355_ST(V, base, p, v) (*reinterpret_cast<V*>(p) = (v))
+#define MI355_OK_AT(base, p, bytes) true
+#endif
 
 // ---- host side ------------------------------------------------------------
 int32_t fail(int32_t code, const char* fmt, ...);

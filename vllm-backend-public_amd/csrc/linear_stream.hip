@@ -53,10 +53,10 @@ __global__ __launch_bounds__(kLinThreads) void linear_stream_kernel(
 
     auto load_w = [&](int s) {
       typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + 32 * s));
+      const u32x4 v = MI355_LDNT(u32x4, w, wp + 32 * s);
       return make_uint4(v.x, v.y, v.z, v.w);
     };
-    auto load_x = [&](int t, int s) { return *reinterpret_cast<const uint4*>(xp[t] + 32 * s); };
+    auto load_x = [&](int t, int s) { return MI355_LD(uint4, x, xp[t] + 32 * s); };
 
     // Two register groups in ping-pong; the prefetch is unconditional (the last
     // iteration re-loads its own group) so that the compiler can count its waits
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kLinThreads) void linear_stream_kernel(
   if (bias != nullptr) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (n0 + r < N) bv[r] = T::to_f(bias[n0 + r]);
+      if (n0 + r < N) bv[r] = T::to_f(MI355_LD(uint16_t, bias, bias + (n0 + r)));
   }
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
@@ -130,11 +130,11 @@ __global__ __launch_bounds__(kLinThreads) void linear_stream_kernel(
                           (static_cast<uint32_t>(T::from_f(acc[t][1] + bv[1])) << 16);
       const uint32_t w1 = static_cast<uint32_t>(T::from_f(acc[t][2] + bv[2])) |
                           (static_cast<uint32_t>(T::from_f(acc[t][3] + bv[3])) << 16);
-      *reinterpret_cast<uint2*>(yp) = make_uint2(w0, w1);
+      MI355_ST(uint2, y, yp, make_uint2(w0, w1));
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (n0 + r < N) yp[r] = T::from_f(acc[t][r] + bv[r]);
+        if (n0 + r < N) MI355_ST(uint16_t, y, yp + r, T::from_f(acc[t][r] + bv[r]));
     }
   }
 }

@@ -104,11 +104,11 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
     for (int i = 0; i < NX; ++i) {
       const int v = i * NT + tid;
       const int row = v / (KSL / 8), col = v % (KSL / 8);
-      xs[i] = *reinterpret_cast<const xvec*>(x + static_cast<int64_t>(min(row, M - 1)) * x_stride +
-                                             static_cast<int64_t>(p) * KSL + col * 8);
+      xs[i] = MI355_LD(xvec, x, x + static_cast<int64_t>(min(row, M - 1)) * x_stride +
+                                    static_cast<int64_t>(p) * KSL + col * 8);
     }
     if (NORM)
-      xs[NXA - 1] = *reinterpret_cast<const xvec*>(fa.norm_w + static_cast<int64_t>(p) * KSL + (tid % (KSL / 8)) * 8);
+      xs[NXA - 1] = MI355_LD(xvec, fa.norm_w, fa.norm_w + static_cast<int64_t>(p) * KSL + (tid % (KSL / 8)) * 8);
     __builtin_amdgcn_sched_barrier(0);
   };
   auto x_commit = [&](xvec (&xs)[NXA], int buf) {
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
     const uint16_t* p = wbase + min(g, groups_total - 1) * gstride;
 #pragma unroll
     for (int u = 0; u < LPG; ++u) {
-      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + u * 512));
+      const u32x4 v = MI355_LDNT(u32x4, wt, p + u * 512);
       wd[u] = make_uint4(v.x, v.y, v.z, v.w);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
               const int q = q0 + 8 * u + j;
-              v[u] = q < fa.norm_parts ? fa.sumsq_in[q * kSumsqRows + row] : 0.f;
+              v[u] = q < fa.norm_parts ? MI355_LD(float, fa.sumsq_in, fa.sumsq_in + (q * kSumsqRows + row)) : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) ss += v[u];
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   const int n0 = tile_raw * 16 + 4 * h;
   const bool live = tile_raw < tiles_total;
   if (W8) {   // per-row weight scales, stored in tiled row order (so interleaved gate/up tiles find theirs)
-    const float4 sc = *reinterpret_cast<const float4*>(fa.w_scale + tile * 16 + 4 * h);
+    const float4 sc = MI355_LD(float4, fa.w_scale, fa.w_scale + tile * 16 + 4 * h);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       acc[m][0] = pin_f32(acc[m][0] * sc.x);   // an fp32 value of its own before any 16-bit rounding
@@ -274,13 +274,13 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
       }
       uint16_t* yp = y + static_cast<int64_t>(mm) * y_stride + j0;
       if (j0 + 3 < F) {
-        *reinterpret_cast<uint2*>(yp) = make_uint2(
+        MI355_ST(uint2, y, yp, make_uint2(
             static_cast<uint32_t>(T::from_f(o[0])) | (static_cast<uint32_t>(T::from_f(o[1])) << 16),
-            static_cast<uint32_t>(T::from_f(o[2])) | (static_cast<uint32_t>(T::from_f(o[3])) << 16));
+            static_cast<uint32_t>(T::from_f(o[2])) | (static_cast<uint32_t>(T::from_f(o[3])) << 16)));
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (j0 + r < F) yp[r] = T::from_f(o[r]);
+          if (j0 + r < F) MI355_ST(uint16_t, y, yp + r, T::from_f(o[r]));
       }
     }
     return;
@@ -299,17 +299,19 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
         float* pp = partial + (static_cast<int64_t>(kgroup) * M + mm) * N + n0;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (n0 + r < N) __hip_atomic_store(pp + r, acc[m][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (n0 + r < N && MI355_OK_AT(partial, pp + r, 4))
+            __hip_atomic_store(pp + r, acc[m][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // every lane's slab stores have completed ...
     __syncthreads();                                          // ... before one lane draws the ticket
     if (tid == 0)
-      last_s = __hip_atomic_fetch_add(&fa.counters[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-               static_cast<unsigned>(kgs - 1);
+      last_s = MI355_OK_AT(fa.counters, fa.counters + blockIdx.x, 4) &&
+               __hip_atomic_fetch_add(&fa.counters[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                   static_cast<unsigned>(kgs - 1);
     __syncthreads();
     if (!last_s) return;
-    if (tid == 0) fa.counters[blockIdx.x] = 0;   // all tickets drawn: re-arm for the next launch
+    if (tid == 0) MI355_ST(unsigned, fa.counters, fa.counters + blockIdx.x, 0u);   // all tickets drawn: re-arm for the next launch
     // this workgroup's NW*16 columns, 8 per thread, NW*2 threads per row, NT / (NW*2) = 32 rows per pass
     constexpr int VPR = NW * 2;
     const int col = blockIdx.x * (NW * 16) + (tid % VPR) * 8;
@@ -324,34 +326,35 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
           const float* p = partial + (static_cast<int64_t>(s) * M + row) * N + col;
           float v[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = __hip_atomic_load(p + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int j = 0; j < 8; ++j)
+            v[j] = MI355_OK_AT(partial, p + j, 4) ? __hip_atomic_load(p + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
 #pragma unroll
           for (int j = 0; j < 8; ++j) f[j] += v[j];
         }
         if (bias != nullptr) {
           float bb[8];
-          unpack8<T>(*reinterpret_cast<const uint4*>(bias + col), bb);
+          unpack8<T>(MI355_LD(uint4, bias, bias + col), bb);
 #pragma unroll
           for (int j = 0; j < 8; ++j) f[j] += bb[j];
         }
         if (EPI == EPI_REDUCE_RESID) {
           uint4* rp = reinterpret_cast<uint4*>(fa.resid + static_cast<int64_t>(row) * fa.resid_stride + col);
           float r[8];
-          unpack8<T>(*rp, r);
+          unpack8<T>(MI355_LD(uint4, fa.resid, rp), r);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             f[j] = round_f<T>(round_f<T>(f[j]) + r[j]);
             ss += f[j] * f[j];
           }
-          *rp = pack8<T>(f);
+          MI355_ST(uint4, fa.resid, rp, pack8<T>(f));
         } else {
-          *reinterpret_cast<uint4*>(y + static_cast<int64_t>(row) * y_stride + col) = pack8<T>(f);
+          MI355_ST(uint4, y, y + static_cast<int64_t>(row) * y_stride + col, pack8<T>(f));
         }
       }
       if (EPI == EPI_REDUCE_RESID) {
 #pragma unroll
         for (int d = 1; d < VPR; d <<= 1) ss += __shfl_xor(ss, d);
-        if (row < M && tid % VPR == 0) fa.sumsq_out[blockIdx.x * kSumsqRows + row] = ss;
+        if (row < M && tid % VPR == 0) MI355_ST(float, fa.sumsq_out, fa.sumsq_out + (blockIdx.x * kSumsqRows + row), ss);
       }
     }
     return;
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   if (EPI == EPI_STORE && bias != nullptr) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (n0 + r < N) bv[r] = T::to_f(bias[n0 + r]);
+      if (n0 + r < N) bv[r] = T::to_f(MI355_LD(uint16_t, bias, bias + (n0 + r)));
   }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -370,22 +373,22 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
     if (EPI == EPI_PARTIAL) {
       float* pp = partial + (static_cast<int64_t>(kgroup) * M + mm) * N + n0;
       if (n0 + 3 < N && (N & 3) == 0) {
-        *reinterpret_cast<float4*>(pp) = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+        MI355_ST(float4, partial, pp, make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]));
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (n0 + r < N) pp[r] = acc[m][r];
+          if (n0 + r < N) MI355_ST(float, partial, pp + r, acc[m][r]);
       }
     } else {
       uint16_t* yp = y + static_cast<int64_t>(mm) * y_stride + n0;
       if (n0 + 3 < N && (y_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0) {
-        *reinterpret_cast<uint2*>(yp) = make_uint2(
+        MI355_ST(uint2, y, yp, make_uint2(
             static_cast<uint32_t>(T::from_f(acc[m][0] + bv[0])) | (static_cast<uint32_t>(T::from_f(acc[m][1] + bv[1])) << 16),
-            static_cast<uint32_t>(T::from_f(acc[m][2] + bv[2])) | (static_cast<uint32_t>(T::from_f(acc[m][3] + bv[3])) << 16));
+            static_cast<uint32_t>(T::from_f(acc[m][2] + bv[2])) | (static_cast<uint32_t>(T::from_f(acc[m][3] + bv[3])) << 16)));
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (n0 + r < N) yp[r] = T::from_f(acc[m][r] + bv[r]);
+          if (n0 + r < N) MI355_ST(uint16_t, y, yp + r, T::from_f(acc[m][r] + bv[r]));
       }
     }
   }
@@ -435,8 +438,8 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled2_kernel(
     for (int i = 0; i < NX; ++i) {
       const int v = i * NT + tid;
       const int row = v / (KSL / 8), col = v % (KSL / 8);
-      xs[i] = *reinterpret_cast<const xvec*>(x + static_cast<int64_t>(min(row, M - 1)) * x_stride +
-                                             static_cast<int64_t>(p) * KSL + col * 8);
+      xs[i] = MI355_LD(xvec, x, x + static_cast<int64_t>(min(row, M - 1)) * x_stride +
+                                    static_cast<int64_t>(p) * KSL + col * 8);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -459,12 +462,12 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled2_kernel(
     const int64_t off = min(g, groups_total - 1) * gstride;
 #pragma unroll
     for (int u = 0; u < LPG; ++u) {
-      const u32x4 v0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase0 + off + u * 512));
+      const u32x4 v0 = MI355_LDNT(u32x4, wt, wbase0 + off + u * 512);
       wd[0][u] = make_uint4(v0.x, v0.y, v0.z, v0.w);
     }
 #pragma unroll
     for (int u = 0; u < LPG; ++u) {
-      const u32x4 v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase1 + off + u * 512));
+      const u32x4 v1 = MI355_LDNT(u32x4, wt, wbase1 + off + u * 512);
       wd[1][u] = make_uint4(v1.x, v1.y, v1.z, v1.w);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled2_kernel(
   if (W8) {
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
-      const float4 sc = *reinterpret_cast<const float4*>(w_scale + (j ? tile1 : tile0) * 16 + 4 * h);
+      const float4 sc = MI355_LD(float4, w_scale, w_scale + (j ? tile1 : tile0) * 16 + 4 * h);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         acc[j][m][0] = pin_f32(acc[j][m][0] * sc.x);
@@ -558,13 +561,13 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled2_kernel(
       for (int r = 0; r < 4; ++r) o[r] = silu_mul<T>(round_f<T>(acc[0][m][r]), round_f<T>(acc[1][m][r]));
       uint16_t* yp = y + static_cast<int64_t>(mm) * y_stride + j0;
       if (j0 + 3 < F) {
-        *reinterpret_cast<uint2*>(yp) = make_uint2(
+        MI355_ST(uint2, y, yp, make_uint2(
             static_cast<uint32_t>(T::from_f(o[0])) | (static_cast<uint32_t>(T::from_f(o[1])) << 16),
-            static_cast<uint32_t>(T::from_f(o[2])) | (static_cast<uint32_t>(T::from_f(o[3])) << 16));
+            static_cast<uint32_t>(T::from_f(o[2])) | (static_cast<uint32_t>(T::from_f(o[3])) << 16)));
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (j0 + r < F) yp[r] = T::from_f(o[r]);
+          if (j0 + r < F) MI355_ST(uint16_t, y, yp + r, T::from_f(o[r]));
       }
     }
     return;
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled2_kernel(
     if (EPI == EPI_STORE && bias != nullptr) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (n0 + r < N) bv[r] = T::to_f(bias[n0 + r]);
+        if (n0 + r < N) bv[r] = T::to_f(MI355_LD(uint16_t, bias, bias + (n0 + r)));
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -586,22 +589,22 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled2_kernel(
       if (EPI == EPI_PARTIAL) {
         float* pp = partial + (static_cast<int64_t>(kgroup) * M + mm) * N + n0;
         if (n0 + 3 < N && (N & 3) == 0) {
-          *reinterpret_cast<float4*>(pp) = make_float4(acc[j][m][0], acc[j][m][1], acc[j][m][2], acc[j][m][3]);
+          MI355_ST(float4, partial, pp, make_float4(acc[j][m][0], acc[j][m][1], acc[j][m][2], acc[j][m][3]));
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (n0 + r < N) pp[r] = acc[j][m][r];
+            if (n0 + r < N) MI355_ST(float, partial, pp + r, acc[j][m][r]);
         }
       } else {
         uint16_t* yp = y + static_cast<int64_t>(mm) * y_stride + n0;
         if (n0 + 3 < N && (y_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0) {
-          *reinterpret_cast<uint2*>(yp) = make_uint2(
+          MI355_ST(uint2, y, yp, make_uint2(
               static_cast<uint32_t>(T::from_f(acc[j][m][0] + bv[0])) | (static_cast<uint32_t>(T::from_f(acc[j][m][1] + bv[1])) << 16),
-              static_cast<uint32_t>(T::from_f(acc[j][m][2] + bv[2])) | (static_cast<uint32_t>(T::from_f(acc[j][m][3] + bv[3])) << 16));
+              static_cast<uint32_t>(T::from_f(acc[j][m][2] + bv[2])) | (static_cast<uint32_t>(T::from_f(acc[j][m][3] + bv[3])) << 16)));
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (n0 + r < N) yp[r] = T::from_f(acc[j][m][r] + bv[r]);
+            if (n0 + r < N) MI355_ST(uint16_t, y, yp + r, T::from_f(acc[j][m][r] + bv[r]));
         }
       }
     }
@@ -629,8 +632,8 @@ __global__ void tile_weights_kernel(uint16_t* __restrict__ dst, const uint16_t* 
       if (row >= N) row = -1;
     }
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (row >= 0) v = *reinterpret_cast<const uint4*>(src + static_cast<int64_t>(row) * K + 32 * ks + 8 * h);
-    *reinterpret_cast<uint4*>(dst + (b * 64 + lane) * 8) = v;
+    if (row >= 0) v = MI355_LD(uint4, src, src + static_cast<int64_t>(row) * K + 32 * ks + 8 * h);
+    MI355_ST(uint4, dst, dst + (b * 64 + lane) * 8, v);
   }
 }
 
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(256) void fp8_row_scale_kernel(float* __restrict__ 
     const uint4* p = reinterpret_cast<const uint4*>(src + static_cast<int64_t>(row) * K);
     for (int v = threadIdx.x; v < (K >> 3); v += 256) {
       float f[8];
-      unpack8<T>(p[v], f);
+      unpack8<T>(MI355_LD(uint4, src, p + v), f);
 #pragma unroll
       for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
     }
@@ -669,7 +672,7 @@ __global__ __launch_bounds__(256) void fp8_row_scale_kernel(float* __restrict__ 
   __syncthreads();
   if (threadIdx.x == 0) {
     amax = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
-    scale_t[tr] = amax > 0.f ? amax / 448.0f : 1.0f;
+    MI355_ST(float, scale_t, scale_t + tr, amax > 0.f ? amax / 448.0f : 1.0f);
   }
 }
 
@@ -686,12 +689,12 @@ __global__ __launch_bounds__(64) void tile_weights_fp8_kernel(unsigned char* __r
     const int row = tiled_source_row(tile, i, N, interleave_halves);
     uint32_t w[4] = {0, 0, 0, 0};
     if (row >= 0) {
-      const float sc = scale_t[tile * 16 + i];
+      const float sc = MI355_LD(float, scale_t, scale_t + (tile * 16 + i));
       const uint16_t* p = src + static_cast<int64_t>(row) * K + 64 * kp + 8 * h;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         float f[8];
-        unpack8<T>(*reinterpret_cast<const uint4*>(p + 32 * half), f);
+        unpack8<T>(MI355_LD(uint4, src, p + 32 * half), f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = f[j] / sc;
         int lo = 0, hi = 0;
@@ -703,7 +706,7 @@ __global__ __launch_bounds__(64) void tile_weights_fp8_kernel(unsigned char* __r
         w[2 * half + 1] = static_cast<uint32_t>(hi);
       }
     }
-    *reinterpret_cast<uint4*>(dst + (b * 64 + lane) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    MI355_ST(uint4, dst, dst + (b * 64 + lane) * 16, make_uint4(w[0], w[1], w[2], w[3]));
   }
 }
 

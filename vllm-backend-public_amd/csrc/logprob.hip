@@ -17,8 +17,8 @@ constexpr int kLseThreads = 1024;
 
 template <int LDT>
 __device__ __forceinline__ float logit_at(const void* row, int i) {
-  if (LDT == MI355_F32) return static_cast<const float*>(row)[i];
-  const uint16_t u = static_cast<const uint16_t*>(row)[i];
+  if (LDT == MI355_F32) return MI355_LD(float, row, static_cast<const float*>(row) + i);
+  const uint16_t u = MI355_LD(uint16_t, row, static_cast<const uint16_t*>(row) + i);
   return LDT == MI355_BF16 ? BF16::to_f(u) : F16::to_f(u);
 }
 
@@ -59,10 +59,11 @@ __global__ __launch_bounds__(kLseThreads) void token_logprob_kernel(float* __res
   sum = block_reduce(sum, false);
   if (threadIdx.x == 0) {
     const float lse = mx + logf(sum);
-    if (out_lse != nullptr) out_lse[row] = lse;
+    if (out_lse != nullptr) MI355_ST(float, out_lse, out_lse + row, lse);
     if (out_logprob != nullptr) {
-      const int64_t id = ids[row];
-      out_logprob[row] = (id >= 0 && id < vocab) ? logit_at<LDT>(base, static_cast<int>(id)) - lse : -INFINITY;
+      const int64_t id = MI355_LD(int64_t, ids, ids + row);
+      MI355_ST(float, out_logprob, out_logprob + row,
+               (id >= 0 && id < vocab) ? logit_at<LDT>(base, static_cast<int>(id)) - lse : -INFINITY);
     }
   }
 }

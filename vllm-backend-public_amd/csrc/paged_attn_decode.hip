@@ -83,17 +83,17 @@ struct Proj8 {
       if (SLABS > 0) {
 #pragma unroll
         for (int s = 0; s < SLABS; ++s) {
-          const float4* p = reinterpret_cast<const float4*>(pr + s * ra.slab_stride);
-          a[s] = p[0];
-          b[s] = p[1];
+          const float* p = pr + s * ra.slab_stride;
+          a[s] = MI355_LD(float4, ra.partial, p);
+          b[s] = MI355_LD(float4, ra.partial, p + 4);
         }
       }
       // branch-free (a branch around a load drains the load queue): without a bias the load
       // goes to the start of the cos/sin table and is multiplied by zero
       has = ra.bias != nullptr ? 1.f : 0.f;
-      raw = *reinterpret_cast<const uint4*>(ra.bias != nullptr ? ra.bias + col : ra.cos_sin);
+      raw = MI355_LD(uint4, ra.bias != nullptr ? ra.bias : ra.cos_sin, ra.bias != nullptr ? ra.bias + col : ra.cos_sin);
     } else {
-      raw = *reinterpret_cast<const uint4*>(q + static_cast<int64_t>(seq) * q_stride + col);
+      raw = MI355_LD(uint4, q, q + static_cast<int64_t>(seq) * q_stride + col);
     }
   }
   __device__ __forceinline__ void finish(float (&f)[8], const RopeArgs& ra) const {
@@ -108,8 +108,8 @@ struct Proj8 {
         }
       } else {
         for (int s = 0; s < ra.num_slabs; ++s) {
-          const float4* p = reinterpret_cast<const float4*>(pr + s * ra.slab_stride);
-          const float4 x = p[0], y = p[1];
+          const float* p = pr + s * ra.slab_stride;
+          const float4 x = MI355_LD(float4, ra.partial, p), y = MI355_LD(float4, ra.partial, p + 4);
           f[0] += x.x; f[1] += x.y; f[2] += x.z; f[3] += x.w;
           f[4] += y.x; f[5] += y.y; f[6] += y.z; f[7] += y.w;
         }
@@ -134,16 +134,17 @@ __device__ __forceinline__ uint16_t load_proj1(const uint16_t* q, int64_t q_stri
     if (SLABS > 0) {
       float v[SLABS > 0 ? SLABS : 1];
 #pragma unroll
-      for (int s = 0; s < SLABS; ++s) v[s] = pr[s * ra.slab_stride];
+      for (int s = 0; s < SLABS; ++s) v[s] = MI355_LD(float, ra.partial, pr + s * ra.slab_stride);
 #pragma unroll
       for (int s = 0; s < SLABS; ++s) f += v[s];
     } else {
-      for (int s = 0; s < ra.num_slabs; ++s) f += pr[s * ra.slab_stride];
+      for (int s = 0; s < ra.num_slabs; ++s) f += MI355_LD(float, ra.partial, pr + s * ra.slab_stride);
     }
-    f += (ra.bias != nullptr ? 1.f : 0.f) * T::to_f(*(ra.bias != nullptr ? ra.bias + col : ra.cos_sin));
+    f += (ra.bias != nullptr ? 1.f : 0.f) *
+         T::to_f(MI355_LD(uint16_t, ra.bias != nullptr ? ra.bias : ra.cos_sin, ra.bias != nullptr ? ra.bias + col : ra.cos_sin));
     return T::from_f(f);
   }
-  return q[static_cast<int64_t>(seq) * q_stride + col];
+  return MI355_LD(uint16_t, q, q + static_cast<int64_t>(seq) * q_stride + col);
 }
 
 // rotate-half rotation of 8 pairs; every product and the sum rounded to the 16-bit type
@@ -185,11 +186,11 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
   int e0 = 0, e1 = 0;
   if (!SPLIT) {   // compile-time: a run-time branch around the loads would drain them at its join
     const int bi = min(2 * wave, max_blocks - 1);
-    e0 = bt[bi];
-    e1 = bt[min(bi + 1, max_blocks - 1)];
+    e0 = MI355_LD(int32_t, block_tables, bt + bi);
+    e1 = MI355_LD(int32_t, block_tables, bt + min(bi + 1, max_blocks - 1));
   }
   __builtin_amdgcn_sched_barrier(0);
-  int ctx = context_lens[seq];
+  int ctx = MI355_LD(int32_t, context_lens, context_lens + seq);
   const int ctx_cap = max_blocks * BS;
   ctx = ctx < 0 ? 0 : (ctx > ctx_cap ? ctx_cap : ctx);
   // token range of this split: multiples of one workgroup pass (4 waves x 32)
@@ -212,21 +213,22 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
         k_cache + ((static_cast<int64_t>(kblk) * num_kv_heads + kvh) * BS + koff) * D + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      r.ka[ks] = *reinterpret_cast<const uint4*>(kp + 32 * ks);
-      r.kb[ks] = *reinterpret_cast<const uint4*>(kp + 4 * D + 32 * ks);
+      r.ka[ks] = MI355_LD(uint4, k_cache, kp + 32 * ks);
+      r.kb[ks] = MI355_LD(uint4, k_cache, kp + 4 * D + 32 * ks);
     }
     const int vblk = (h & 2) ? blk1 : blk0;
     const uint16_t* vp =
         v_cache + ((static_cast<int64_t>(vblk) * num_kv_heads + kvh) * D + c) * BS + 8 * (h & 1);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) r.vf[n] = *reinterpret_cast<const uint4*>(vp + n * 16 * BS);
+    for (int n = 0; n < NT; ++n) r.vf[n] = MI355_LD(uint4, v_cache, vp + n * 16 * BS);
   };
   // Always issued, never inside a branch (a load inside a branch makes the compiler drain the load
   // queue at the join): a step beyond the wave's range reads the context's last pages, which the
   // cache holds, and is never used.
   auto issue_loads = [&](KVRegs<KS, NT>& r, int tb) {
     const int bi = min(tb / BS, last_blk_idx);
-    issue_page_loads(r, bt[bi], bt[min(bi + 1, last_blk_idx)]);
+    issue_page_loads(r, MI355_LD(int32_t, block_tables, bt + bi),
+                     MI355_LD(int32_t, block_tables, bt + min(bi + 1, last_blk_idx)));
   };
   int tb = t_begin + kStep * wave;
   if (!SPLIT) {
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
     if (c < group) {
       const uint16_t* qp = q + seq * q_stride + static_cast<int64_t>(kvh * group + c) * D + 8 * h;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(qp + 32 * ks);
+      for (int ks = 0; ks < KS; ++ks) qf[ks] = MI355_LD(uint4, q, qp + 32 * ks);
     }
   } else {
     const int width = (num_heads + 2 * num_kv_heads) * D;
@@ -261,13 +263,13 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
     // (lanes beyond the group and workgroups that do not own the new token compute values they
     // drop): the rotation then waits once, not once per branch or per chunk.
     const int hq = c < group ? c : 0;
-    const int64_t slot = ra.slots[seq];
+    const int64_t slot = MI355_LD(int64_t, ra.slots, ra.slots + seq);
     Proj8<T, FUSE, SLABS> pq1[KS / 2], pq2[KS / 2], pk1[KS / 2], pk2[KS / 2];
     uint4 cosr[KS / 2], sinr[KS / 2];
 #pragma unroll
     for (int ks = 0; ks < KS / 2; ++ks) {
-      cosr[ks] = *reinterpret_cast<const uint4*>(cs + 32 * ks + 8 * h);
-      sinr[ks] = *reinterpret_cast<const uint4*>(cs + D / 2 + 32 * ks + 8 * h);
+      cosr[ks] = MI355_LD(uint4, ra.cos_sin, cs + 32 * ks + 8 * h);
+      sinr[ks] = MI355_LD(uint4, ra.cos_sin, cs + D / 2 + 32 * ks + 8 * h);
       const int col = (kvh * group + hq) * D + 8 * h + 32 * ks;
       pq1[ks].issue(q, q_stride, ra, seq, width, col);
       pq2[ks].issue(q, q_stride, ra, seq, width, col + D / 2);
@@ -303,12 +305,12 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
         if (c == 0) {                                // lanes h = 0..3 hold the whole k row between them
           uint16_t* dst = k_cache + ((blk * num_kv_heads + kvh) * BS + off) * D + 8 * h;
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) *reinterpret_cast<uint4*>(dst + 32 * ks) = knew[ks];
+          for (int ks = 0; ks < KS; ++ks) MI355_ST(uint4, k_cache, dst + 32 * ks, knew[ks]);
         }
         if (h == 0) {                                // lanes c = 0..15 hold v[16n + c]
           uint16_t* dst = v_cache + (blk * num_kv_heads + kvh) * D * BS + off;
 #pragma unroll
-          for (int n = 0; n < NT; ++n) dst[static_cast<int64_t>(16 * n + c) * BS] = vnew[n];
+          for (int n = 0; n < NT; ++n) MI355_ST(uint16_t, v_cache, dst + static_cast<int64_t>(16 * n + c) * BS, vnew[n]);
         }
       }
     }
@@ -451,13 +453,14 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
     const int head = kvh * group + hh;
     if (num_splits == 1) {
       const float val = lsum > 0.f ? acc / lsum : 0.f;
-      out[(static_cast<int64_t>(seq) * num_heads + head) * D + d] = T::from_f(val);
+      MI355_ST(uint16_t, out, out + (static_cast<int64_t>(seq) * num_heads + head) * D + d, T::from_f(val));
     } else {
+      // the partials are one buffer: [rows][splits][D] accumulators, then [rows][splits][2] statistics
       const int64_t pi = (static_cast<int64_t>(seq) * num_heads + head) * num_splits + split;
-      part_o[pi * D + d] = acc;
+      MI355_ST(float, part_o, part_o + pi * D + d, acc);
       if (d == 0) {
-        part_ml[pi * 2] = mg;
-        part_ml[pi * 2 + 1] = lsum;
+        MI355_ST(float, part_o, part_ml + pi * 2, mg);
+        MI355_ST(float, part_o, part_ml + pi * 2 + 1, lsum);
       }
     }
   }
@@ -473,16 +476,16 @@ __global__ __launch_bounds__(D) void paged_attn_merge_kernel(uint16_t* __restric
   const int d = threadIdx.x;
   const float* ml = part_ml + row * num_splits * 2;
   float mg = -INFINITY;
-  for (int s = 0; s < num_splits; ++s) mg = fmaxf(mg, ml[2 * s]);
+  for (int s = 0; s < num_splits; ++s) mg = fmaxf(mg, MI355_LD(float, part_o, ml + 2 * s));
   float acc = 0.f, lsum = 0.f;
   if (mg != -INFINITY) {
     for (int s = 0; s < num_splits; ++s) {
-      const float f = exp2f(ml[2 * s] - mg);
-      acc += f * part_o[(row * num_splits + s) * D + d];
-      lsum += f * ml[2 * s + 1];
+      const float f = exp2f(MI355_LD(float, part_o, ml + 2 * s) - mg);
+      acc += f * MI355_LD(float, part_o, part_o + (row * num_splits + s) * D + d);
+      lsum += f * MI355_LD(float, part_o, ml + 2 * s + 1);
     }
   }
-  out[row * D + d] = T::from_f(lsum > 0.f ? acc / lsum : 0.f);
+  MI355_ST(uint16_t, out, out + row * D + d, T::from_f(lsum > 0.f ? acc / lsum : 0.f));
 }
 
 template <typename T, int D, int FUSE, int SLABS = 0>

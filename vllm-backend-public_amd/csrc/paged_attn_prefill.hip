@@ -65,11 +65,11 @@ __global__ __launch_bounds__(kPrefillThreads) void paged_attn_prefill_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, h = lane >> 4;
 
-  const int q_begin = cu_seqlens[seq];
-  const int q_len = cu_seqlens[seq + 1] - q_begin;
+  const int q_begin = MI355_LD(int32_t, cu_seqlens, cu_seqlens + seq);
+  const int q_len = MI355_LD(int32_t, cu_seqlens, cu_seqlens + seq + 1) - q_begin;
   const int q0 = qtile * qt;
   if (q0 >= q_len) return;                       // whole workgroup: no barrier is skipped by some threads only
-  int ctx = context_lens[seq];
+  int ctx = MI355_LD(int32_t, context_lens, context_lens + seq);
   const int ctx_cap = max_blocks * BS;
   ctx = ctx > ctx_cap ? ctx_cap : ctx;
   const int pos0 = ctx - q_len;                  // absolute position of the chunk's first query
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kPrefillThreads) void paged_attn_prefill_kernel(
                          static_cast<int64_t>(col_ok[t] ? col_head[t] : 0) * D + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const uint4 v = *reinterpret_cast<const uint4*>(qp + 32 * ks);     // always a valid row; dropped if not ours
+      const uint4 v = MI355_LD(uint4, q, qp + 32 * ks);     // always a valid row; dropped if not ours
       *reinterpret_cast<uint4*>(qlds + (t * KS + ks) * 1024) = col_ok[t] ? v : make_uint4(0, 0, 0, 0);
     }
   }
@@ -136,14 +136,14 @@ __global__ __launch_bounds__(kPrefillThreads) void paged_attn_prefill_kernel(
   auto stage_load = [&](pvec (&regs)[PPT], int tb, auto np) {
     constexpr int NP = decltype(np)::value;
     const int bi = min(tb / BS, last_blk_idx);
-    int blk[2] = {bt[bi], bt[min(bi + 1, last_blk_idx)]};
+    int blk[2] = {MI355_LD(int32_t, block_tables, bt + bi), MI355_LD(int32_t, block_tables, bt + min(bi + 1, last_blk_idx))};
     blk[0] = min(max(blk[0], 0), num_blocks - 1);
     blk[1] = min(max(blk[1], 0), num_blocks - 1);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int64_t page = (static_cast<int64_t>(blk[src_page[j]]) * num_kv_heads + kvh) * (BS * D);
       const uint16_t* src = (j < PPT / 2 ? k_cache : v_cache) + page + src_off[j];
-      regs[j] = *reinterpret_cast<const pvec*>(src);
+      regs[j] = MI355_LD(pvec, j < PPT / 2 ? k_cache : v_cache, src);
     }
   };
   auto stage_store = [&](const pvec (&regs)[PPT], int buf, auto np) {
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kPrefillThreads) void paged_attn_prefill_kernel(
                           (static_cast<uint32_t>(T::from_f(o[t][n][1] * inv)) << 16);
       const uint32_t w1 = static_cast<uint32_t>(T::from_f(o[t][n][2] * inv)) |
                           (static_cast<uint32_t>(T::from_f(o[t][n][3] * inv)) << 16);
-      *reinterpret_cast<uint2*>(op + 16 * n) = make_uint2(w0, w1);
+      MI355_ST(uint2, out, op + 16 * n, make_uint2(w0, w1));
     }
   }
 }

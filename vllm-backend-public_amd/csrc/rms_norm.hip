@@ -41,27 +41,27 @@ __global__ __launch_bounds__(kThreads) void rms_norm_kernel(
       for (int j = 0; j < 8; ++j) f[j] = 0.f;
       for (int s = 0; s < num_slabs; ++s) {
         const float4* p = reinterpret_cast<const float4*>(pr + s * slab_stride + 8 * v);
-        const float4 a = p[0], b = p[1];
+        const float4 a = MI355_LD(float4, partial, p), b = MI355_LD(float4, partial, p + 1);
         f[0] += a.x; f[1] += a.y; f[2] += a.z; f[3] += a.w;
         f[4] += b.x; f[5] += b.y; f[6] += b.z; f[7] += b.w;
       }
       if (bias != nullptr) {
         float bb[8];
-        unpack8<T>(reinterpret_cast<const uint4*>(bias)[v], bb);
+        unpack8<T>(MI355_LD(uint4, bias, reinterpret_cast<const uint4*>(bias) + v), bb);
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] += bb[j];
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = round_f<T>(f[j]);
     } else {
-      unpack8<T>(xr[v], f);
+      unpack8<T>(MI355_LD(uint4, x, xr + v), f);
     }
     if (ADD) {
       float r[8];
-      unpack8<T>(rr[v], r);
+      unpack8<T>(MI355_LD(uint4, residual, rr + v), r);
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = round_f<T>(f[j] + r[j]);
-      rr[v] = pack8<T>(f);
+      MI355_ST(uint4, residual, rr + v, pack8<T>(f));
     }
   };
 
@@ -95,10 +95,10 @@ __global__ __launch_bounds__(kThreads) void rms_norm_kernel(
 
   auto finish = [&](int v, const float (&f)[8]) {
     float w[8], y[8];
-    unpack8<T>(wv[v], w);
+    unpack8<T>(MI355_LD(uint4, weight, wv + v), w);
 #pragma unroll
     for (int j = 0; j < 8; ++j) y[j] = round_f<T>(f[j] * inv) * w[j];
-    orow[v] = pack8<T>(y);
+    MI355_ST(uint4, out, orow + v, pack8<T>(y));
   };
 
   if (CACHED) {
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kThreads) void rms_norm_kernel(
     const uint4* src = ADD ? rr : xr;
     for (int v = threadIdx.x; v < nvec; v += kThreads) {
       float f[8];
-      unpack8<T>(src[v], f);
+      unpack8<T>(MI355_LD(uint4, ADD ? residual : x, src + v), f);
       finish(v, f);
     }
   }
@@ -149,13 +149,13 @@ __global__ __launch_bounds__(kThreads) void rms_norm_slabs_kernel(
 #pragma unroll
     for (int s = 0; s < SLABS; ++s) {
       const float4* p = reinterpret_cast<const float4*>(pr + s * slab_stride + 8 * v);
-      a[i][s][0] = p[0];
-      a[i][s][1] = p[1];
+      a[i][s][0] = MI355_LD(float4, partial, p);
+      a[i][s][1] = MI355_LD(float4, partial, p + 1);
     }
-    if (SLABS == 0) xv[i] = xr[v];
-    res[i] = rr[v];
-    br[i] = bv[v];
-    wr[i] = wv[v];
+    if (SLABS == 0) xv[i] = MI355_LD(uint4, x16, xr + v);
+    res[i] = MI355_LD(uint4, residual, rr + v);
+    br[i] = MI355_LD(uint4, bias != nullptr ? bias : weight, bv + v);
+    wr[i] = MI355_LD(uint4, weight, wv + v);
   }
   __builtin_amdgcn_sched_barrier(0);
 
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kThreads) void rms_norm_slabs_kernel(
       }
     }
     if (v < nvec) {
-      rr[v] = pack8<T>(f[i]);
+      MI355_ST(uint4, residual, rr + v, pack8<T>(f[i]));
 #pragma unroll
       for (int j = 0; j < 8; ++j) ss += f[i][j] * f[i][j];
     }
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void rms_norm_slabs_kernel(
     unpack8<T>(wr[i], w);
 #pragma unroll
     for (int j = 0; j < 8; ++j) y[j] = round_f<T>(f[i][j] * inv) * w[j];
-    if (v < nvec) orow[v] = pack8<T>(y);
+    if (v < nvec) MI355_ST(uint4, out, orow + v, pack8<T>(y));
   }
 }
 
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kThreads) void embed_rms_norm_kernel(
     const int64_t* __restrict__ ids, int64_t vocab, const uint16_t* __restrict__ weight, int hidden,
     int64_t embed_stride, int64_t out_stride, int64_t res_stride, float eps) {
   const int64_t row = blockIdx.x;
-  int64_t id = ids[row];
+  int64_t id = MI355_LD(int64_t, ids, ids + row);
   id = (id < 0 || id >= vocab) ? 0 : id;
   const int nvec = hidden >> 3;
   const uint4* er = reinterpret_cast<const uint4*>(embed + id * embed_stride);
@@ -230,8 +230,8 @@ __global__ __launch_bounds__(kThreads) void embed_rms_norm_kernel(
   const uint4* wv = reinterpret_cast<const uint4*>(weight);
   float ss = 0.f;
   for (int v = threadIdx.x; v < nvec; v += kThreads) {
-    const uint4 raw = er[v];
-    rr[v] = raw;
+    const uint4 raw = MI355_LD(uint4, embed, er + v);
+    MI355_ST(uint4, residual, rr + v, raw);
     float f[8];
     unpack8<T>(raw, f);
 #pragma unroll
@@ -247,11 +247,11 @@ __global__ __launch_bounds__(kThreads) void embed_rms_norm_kernel(
   const float inv = 1.0f / sqrtf(total / static_cast<float>(hidden) + eps);
   for (int v = threadIdx.x; v < nvec; v += kThreads) {
     float f[8], w[8], y[8];
-    unpack8<T>(er[v], f);                 // an L2 hit: this thread just read it
-    unpack8<T>(wv[v], w);
+    unpack8<T>(MI355_LD(uint4, embed, er + v), f);                 // an L2 hit: this thread just read it
+    unpack8<T>(MI355_LD(uint4, weight, wv + v), w);
 #pragma unroll
     for (int j = 0; j < 8; ++j) y[j] = round_f<T>(f[j] * inv) * w[j];
-    orow[v] = pack8<T>(y);
+    MI355_ST(uint4, out, orow + v, pack8<T>(y));
   }
 }
 

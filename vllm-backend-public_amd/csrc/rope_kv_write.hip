@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(
       for (int s = 0; s < num_slabs; ++s) {
         const float4* a = reinterpret_cast<const float4*>(pr + s * slab_stride);
         const float4* b = reinterpret_cast<const float4*>(pr + s * slab_stride + half);
-        const float4 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+        const float4 a0 = MI355_LD(float4, partial, a), a1 = MI355_LD(float4, partial, a + 1),
+                     b0 = MI355_LD(float4, partial, b), b1 = MI355_LD(float4, partial, b + 1);
         f1[0] += a0.x; f1[1] += a0.y; f1[2] += a0.z; f1[3] += a0.w;
         f1[4] += a1.x; f1[5] += a1.y; f1[6] += a1.z; f1[7] += a1.w;
         f2[0] += b0.x; f2[1] += b0.y; f2[2] += b0.z; f2[3] += b0.w;
@@ -59,8 +60,8 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(
       }
       if (bias != nullptr) {
         float b1[8], b2[8];
-        unpack8<T>(*reinterpret_cast<const uint4*>(bias + col), b1);
-        unpack8<T>(*reinterpret_cast<const uint4*>(bias + col + half), b2);
+        unpack8<T>(MI355_LD(uint4, bias, bias + col), b1);
+        unpack8<T>(MI355_LD(uint4, bias, bias + col + half), b2);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           f1[j] += b1[j];
@@ -70,20 +71,20 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(
       r1 = pack8<T>(f1);
       r2 = pack8<T>(f2);
     } else {
-      r1 = *p1;
-      r2 = *p2;
+      r1 = MI355_LD(uint4, qkv, p1);
+      r2 = MI355_LD(uint4, qkv, p2);
     }
 
     const bool is_v = head >= num_heads + num_kv_heads;
     if (!is_v) {
-      int64_t pos = positions[tok];
+      int64_t pos = MI355_LD(int64_t, positions, positions + tok);
       pos = pos < 0 ? 0 : (pos >= max_position ? max_position - 1 : pos);
       const uint16_t* cs = cos_sin + pos * head_dim;
       float x1[8], x2[8], co[8], si[8];
       unpack8<T>(r1, x1);
       unpack8<T>(r2, x2);
-      unpack8<T>(*reinterpret_cast<const uint4*>(cs + 8 * c), co);
-      unpack8<T>(*reinterpret_cast<const uint4*>(cs + half + 8 * c), si);
+      unpack8<T>(MI355_LD(uint4, cos_sin, cs + 8 * c), co);
+      unpack8<T>(MI355_LD(uint4, cos_sin, cs + half + 8 * c), si);
       float o1[8], o2[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -96,23 +97,23 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(
       }
       r1 = pack8<T>(o1);
       r2 = pack8<T>(o2);
-      *p1 = r1;
-      *p2 = r2;
+      MI355_ST(uint4, qkv, p1, r1);
+      MI355_ST(uint4, qkv, p2, r2);
     } else if (PART) {
-      *p1 = r1;
-      *p2 = r2;
+      MI355_ST(uint4, qkv, p1, r1);
+      MI355_ST(uint4, qkv, p2, r2);
     }
     if (head < num_heads) continue;
 
-    const int64_t slot = slot_mapping[tok];
+    const int64_t slot = MI355_LD(int64_t, slot_mapping, slot_mapping + tok);
     if (slot < 0 || slot >= static_cast<int64_t>(num_blocks) * BS) continue;
     const int64_t blk = slot / BS;
     const int off = static_cast<int>(slot % BS);
     if (!is_v) {
       const int kvh = head - num_heads;
       uint16_t* dst = k_cache + ((blk * num_kv_heads + kvh) * BS + off) * head_dim;
-      *reinterpret_cast<uint4*>(dst + 8 * c) = r1;
-      *reinterpret_cast<uint4*>(dst + half + 8 * c) = r2;
+      MI355_ST(uint4, k_cache, dst + 8 * c, r1);
+      MI355_ST(uint4, k_cache, dst + half + 8 * c, r2);
     } else {
       const int kvh = head - num_heads - num_kv_heads;
       uint16_t* dst = v_cache + (blk * num_kv_heads + kvh) * head_dim * BS + off;
@@ -122,8 +123,8 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(
       for (int j = 0; j < 8; ++j) {
         const uint16_t e1 = static_cast<uint16_t>(j & 1 ? w1[j >> 1] >> 16 : w1[j >> 1] & 0xFFFFu);
         const uint16_t e2 = static_cast<uint16_t>(j & 1 ? w2[j >> 1] >> 16 : w2[j >> 1] & 0xFFFFu);
-        dst[static_cast<int64_t>(8 * c + j) * BS] = e1;
-        dst[static_cast<int64_t>(half + 8 * c + j) * BS] = e2;
+        MI355_ST(uint16_t, v_cache, dst + static_cast<int64_t>(8 * c + j) * BS, e1);
+        MI355_ST(uint16_t, v_cache, dst + static_cast<int64_t>(half + 8 * c + j) * BS, e2);
       }
     }
   }

@@ -42,26 +42,26 @@ __global__ __launch_bounds__(kArgmaxThreads) void argmax_kernel(int64_t* __restr
     const float* p = static_cast<const float*>(logits) + row * stride;
     const int nvec = vocab >> 2;
     for (int v = threadIdx.x; v < nvec; v += kArgmaxThreads) {
-      const float4 f = *reinterpret_cast<const float4*>(p + 4 * v);
+      const float4 f = MI355_LD(float4, logits, p + 4 * v);
       best = umax64(best, argmax_key(f.x, 4 * v));
       best = umax64(best, argmax_key(f.y, 4 * v + 1));
       best = umax64(best, argmax_key(f.z, 4 * v + 2));
       best = umax64(best, argmax_key(f.w, 4 * v + 3));
     }
     for (int i = (nvec << 2) + threadIdx.x; i < vocab; i += kArgmaxThreads)
-      best = umax64(best, argmax_key(p[i], i));
+      best = umax64(best, argmax_key(MI355_LD(float, logits, p + i), i));
   } else {
     const uint16_t* p = static_cast<const uint16_t*>(logits) + row * stride;
     const int nvec = vocab >> 3;
     for (int v = threadIdx.x; v < nvec; v += kArgmaxThreads) {
       float f[8];
-      const uint4 raw = *reinterpret_cast<const uint4*>(p + 8 * v);
+      const uint4 raw = MI355_LD(uint4, logits, p + 8 * v);
       if (LDT == MI355_BF16) unpack8<BF16>(raw, f); else unpack8<F16>(raw, f);
 #pragma unroll
       for (int j = 0; j < 8; ++j) best = umax64(best, argmax_key(f[j], 8 * v + j));
     }
     for (int i = (nvec << 3) + threadIdx.x; i < vocab; i += kArgmaxThreads) {
-      const float f = (LDT == MI355_BF16) ? BF16::to_f(p[i]) : F16::to_f(p[i]);
+      const float f = (LDT == MI355_BF16) ? BF16::to_f(MI355_LD(uint16_t, logits, p + i)) : F16::to_f(MI355_LD(uint16_t, logits, p + i));
       best = umax64(best, argmax_key(f, i));
     }
   }
@@ -78,9 +78,9 @@ __global__ __launch_bounds__(kArgmaxThreads) void argmax_kernel(int64_t* __restr
     if (KEYED) {
       const unsigned long long moved = (b & 0xFFFFFFFF00000000ull) |
                                        static_cast<unsigned long long>(0xFFFFFFFFu - (idx + index_offset));
-      out[row] = static_cast<int64_t>(moved ^ 0x8000000000000000ull);
+      MI355_ST(int64_t, out, out + row, static_cast<int64_t>(moved ^ 0x8000000000000000ull));
     } else {
-      out[row] = static_cast<int64_t>(idx);
+      MI355_ST(int64_t, out, out + row, static_cast<int64_t>(idx));
     }
   }
 }
@@ -102,26 +102,26 @@ __global__ __launch_bounds__(256) void argmax_chunk_kernel(unsigned long long* _
   if (LDT == MI355_F32) {
     const float* p = static_cast<const float*>(logits) + row * stride;
     for (int v = v0 + threadIdx.x; v < v1; v += 256) {
-      const float4 f = *reinterpret_cast<const float4*>(p + 4 * v);
+      const float4 f = MI355_LD(float4, logits, p + 4 * v);
       best = umax64(best, argmax_key(f.x, 4 * v));
       best = umax64(best, argmax_key(f.y, 4 * v + 1));
       best = umax64(best, argmax_key(f.z, 4 * v + 2));
       best = umax64(best, argmax_key(f.w, 4 * v + 3));
     }
     if (blockIdx.y == gridDim.y - 1)
-      for (int i = nvec * PER + threadIdx.x; i < vocab; i += 256) best = umax64(best, argmax_key(p[i], i));
+      for (int i = nvec * PER + threadIdx.x; i < vocab; i += 256) best = umax64(best, argmax_key(MI355_LD(float, logits, p + i), i));
   } else {
     const uint16_t* p = static_cast<const uint16_t*>(logits) + row * stride;
     for (int v = v0 + threadIdx.x; v < v1; v += 256) {
       float f[8];
-      const uint4 raw = *reinterpret_cast<const uint4*>(p + 8 * v);
+      const uint4 raw = MI355_LD(uint4, logits, p + 8 * v);
       if (LDT == MI355_BF16) unpack8<BF16>(raw, f); else unpack8<F16>(raw, f);
 #pragma unroll
       for (int j = 0; j < 8; ++j) best = umax64(best, argmax_key(f[j], 8 * v + j));
     }
     if (blockIdx.y == gridDim.y - 1)
       for (int i = nvec * PER + threadIdx.x; i < vocab; i += 256) {
-        const float f = (LDT == MI355_BF16) ? BF16::to_f(p[i]) : F16::to_f(p[i]);
+        const float f = (LDT == MI355_BF16) ? BF16::to_f(MI355_LD(uint16_t, logits, p + i)) : F16::to_f(MI355_LD(uint16_t, logits, p + i));
         best = umax64(best, argmax_key(f, i));
       }
   }
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void argmax_chunk_kernel(unsigned long long* _
   __syncthreads();
   if (threadIdx.x == 0) {
     best = umax64(umax64(part[0], part[1]), umax64(part[2], part[3]));
-    if (best != 0ull) atomicMax(&keys[row], best);   // 0 = an empty column range (every real key is > 0)
+    if (best != 0ull && MI355_OK_AT(keys, keys + row, 8)) atomicMax(&keys[row], best);   // 0 = an empty column range (every real key is > 0)
   }
 }
 
@@ -140,16 +140,17 @@ __global__ void argmax_finish_kernel(int64_t* __restrict__ out, int64_t* __restr
                                      unsigned long long* __restrict__ keys, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const unsigned long long b = keys[i];
-  keys[i] = 0ull;                                     // re-armed for the next launch
+  const unsigned long long b = MI355_LD(unsigned long long, keys, keys + i);
+  MI355_ST(unsigned long long, keys, keys + i, 0ull);                                   // re-armed for the next launch
   const int64_t idx = static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(b & 0xFFFFFFFFull));
-  out[i] = idx;
-  if (out2 != nullptr) out2[i] = idx;
+  MI355_ST(int64_t, out, out + i, idx);
+  if (out2 != nullptr) MI355_ST(int64_t, out2, out2 + i, idx);
 }
 
 __global__ void argmax_key_to_index_kernel(int64_t* __restrict__ out, const int64_t* __restrict__ keys, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(static_cast<unsigned long long>(keys[i]) & 0xFFFFFFFFull));
+  if (i < n)
+    MI355_ST(int64_t, out, out + i, static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(static_cast<unsigned long long>(MI355_LD(int64_t, keys, keys + i)) & 0xFFFFFFFFull)));
 }
 
 
@@ -187,8 +188,8 @@ __device__ __forceinline__ float key_to_logit(uint32_t k) {
 
 template <int LDT>
 __device__ __forceinline__ float load_logit(const void* row, int i) {
-  if (LDT == MI355_F32) return static_cast<const float*>(row)[i];
-  const uint16_t raw = static_cast<const uint16_t*>(row)[i];
+  if (LDT == MI355_F32) return MI355_LD(float, row, static_cast<const float*>(row) + i);
+  const uint16_t raw = MI355_LD(uint16_t, row, static_cast<const uint16_t*>(row) + i);
   return LDT == MI355_BF16 ? BF16::to_f(raw) : F16::to_f(raw);
 }
 
@@ -237,13 +238,13 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
     const int64_t* __restrict__ seeds, const int64_t* __restrict__ steps) {
 #pragma clang fp contract(off)
   const int row = blockIdx.x;
-  const float temp = temperature[row];
+  const float temp = MI355_LD(float, temperature, temperature + row);
   if (!(temp > 0.0f)) return;  // greedy rows keep the argmax written before
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const void* base = LDT == MI355_F32
                          ? static_cast<const void*>(static_cast<const float*>(logits) + row * stride)
                          : static_cast<const void*>(static_cast<const uint16_t*>(logits) + row * stride);
-  int k = top_k[row];
+  int k = MI355_LD(int32_t, top_k, top_k + row);
   k = (k > 0 && k <= kSampleKMax) ? k : kSampleKMax;
   k = min(k, vocab);
 
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
   }
   __syncthreads();
   if (tid == 0 && static_cast<uint32_t>(comp[0] >> 32) == 0xFFFFFFFFu) {   // a NaN logit: its index, like argmax
-    out[row] = static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(comp[0] & 0xFFFFFFFFull));
+    MI355_ST(int64_t, out, out + row, static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(comp[0] & 0xFFFFFFFFull)));
   } else if (tid == 0) {
     float acc = 0.0f;
     for (int i = 0; i < k; ++i) {
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
       csum[i] = acc;
     }
     int keep = k;
-    const float tp = top_p[row];
+    const float tp = MI355_LD(float, top_p, top_p + row);
     if (tp < 1.0f) {
       const float thr = tp * csum[k - 1];
       for (int i = 0; i < k; ++i)
@@ -365,7 +366,8 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
           break;
         }
     }
-    const float target = sample_uniform(static_cast<uint64_t>(seeds[row]), static_cast<uint64_t>(steps[row])) *
+    const float target = sample_uniform(static_cast<uint64_t>(MI355_LD(int64_t, seeds, seeds + row)),
+                                        static_cast<uint64_t>(MI355_LD(int64_t, steps, steps + row))) *
                          csum[keep - 1];
     int pick = keep - 1;
     for (int i = 0; i < keep; ++i)
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
         pick = i;
         break;
       }
-    out[row] = static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(comp[pick] & 0xFFFFFFFFull));
+    MI355_ST(int64_t, out, out + row, static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(comp[pick] & 0xFFFFFFFFull)));
   }
 }
 

@@ -17,11 +17,11 @@ __global__ __launch_bounds__(256) void silu_and_mul_kernel(uint16_t* __restrict_
     const int v = static_cast<int>(i % vec_per_row);
     const uint16_t* xr = x + row * x_stride;
     float g[8], u[8], y[8];
-    unpack8<T>(*reinterpret_cast<const uint4*>(xr + 8 * v), g);
-    unpack8<T>(*reinterpret_cast<const uint4*>(xr + inter + 8 * v), u);
+    unpack8<T>(MI355_LD(uint4, x, xr + 8 * v), g);
+    unpack8<T>(MI355_LD(uint4, x, xr + inter + 8 * v), u);
 #pragma unroll
     for (int j = 0; j < 8; ++j) y[j] = silu_mul<T>(g[j], u[j]);
-    *reinterpret_cast<uint4*>(out + row * inter + 8 * v) = pack8<T>(y);
+    MI355_ST(uint4, out, out + row * inter + 8 * v, pack8<T>(y));
   }
 }
 

@@ -38,6 +38,9 @@ def _load() -> ctypes.CDLL:
         "mi355_abi_version": (I32, []),
         "mi355_last_error": (c_char_p, []),
         "mi355_target_arch": (c_char_p, []),
+        "mi355_bounds_enabled": (I32, []),
+        "mi355_bounds_set_ranges": (I32, [P, I32]),
+        "mi355_bounds_report": (I32, [P, P, I32]),
         "mi355_rms_norm": (I32, [P, P, P, I64, I32, I64, I64, F, I32, P]),
         "mi355_fused_add_rms_norm": (I32, [P, P, P, P, I64, I32, I64, I64, I64, F, I32, P]),
         "mi355_rope_kv_write": (I32, [P, I64, P, P, I32, P, P, P, I32, I64, I32, I32, I32, I32, P]),
@@ -86,7 +89,8 @@ def _load() -> ctypes.CDLL:
 
 
 lib = _load()
-EXPORTS = ("mi355_abi_version", "mi355_last_error", "mi355_target_arch", "mi355_rms_norm",
+EXPORTS = ("mi355_abi_version", "mi355_last_error", "mi355_target_arch",
+           "mi355_bounds_enabled", "mi355_bounds_set_ranges", "mi355_bounds_report", "mi355_rms_norm",
            "mi355_fused_add_rms_norm", "mi355_rope_kv_write", "mi355_paged_attn_decode_workspace",
            "mi355_paged_attn_decode", "mi355_paged_attn_decode_static", "mi355_paged_attn_prefill", "mi355_silu_and_mul", "mi355_argmax",
            "mi355_argmax_chunked", "mi355_embed_rms_norm",
