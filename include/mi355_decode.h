@@ -121,6 +121,47 @@ int32_t mi355_embed_rms_norm(void* out, void* residual, const void* embed,
                              void* stream);
 
 /*
+ * LayerNorm with weight and bias, the norm of OPT-style decoders (the model the harness
+ * launches with its defaults, benchmark-vllm/models.py:7 model_name "facebook/opt-125m"):
+ *   y = round(((x - mean) * rsqrt(var + eps)) * weight + bias),  var = mean((x - mean)^2),
+ * statistics and the affine map in fp32, one rounding -- what the engine's LayerNorm computes on
+ * a 16-bit tensor.  x, out [num_tokens, hidden] with the given row strides (out may alias x);
+ * weight, bias [hidden].
+ */
+int32_t mi355_layer_norm(void* out, const void* x, const void* weight, const void* bias, int64_t num_tokens,
+                         int32_t hidden, int64_t x_stride, int64_t out_stride, float eps, int32_t dtype,
+                         void* stream);
+
+/*
+ * residual = round(x + residual) (in place), out = layer_norm(residual): the residual add of a
+ * decoder layer and the norm that follows it, one pass.
+ */
+int32_t mi355_fused_add_layer_norm(void* out, const void* x, void* residual, const void* weight,
+                                   const void* bias, int64_t num_tokens, int32_t hidden, int64_t x_stride,
+                                   int64_t out_stride, int64_t residual_stride, float eps, int32_t dtype,
+                                   void* stream);
+
+/*
+ * First kernel of an OPT-style step: residual[t] = round(embed[token_ids[t]] + pos_embed[positions[t]
+ * + position_offset]) (learned positions; OPT stores them with an offset of 2), out[t] =
+ * layer_norm(residual[t]) with the first layer's norm.  embed [vocab, hidden], pos_embed
+ * [num_positions, hidden] with the given row strides.  An id outside [0, vocab) reads row 0, a
+ * position outside the table its nearest row (padded rows of a batch bucket may hold anything).
+ */
+int32_t mi355_embed_pos_layer_norm(void* out, void* residual, const void* embed, const int64_t* token_ids,
+                                   int64_t vocab, int64_t embed_stride, const void* pos_embed,
+                                   const int64_t* positions, int64_t num_positions, int64_t position_offset,
+                                   int64_t pos_stride, const void* weight, const void* bias,
+                                   int64_t num_tokens, int32_t hidden, int64_t out_stride,
+                                   int64_t residual_stride, float eps, int32_t dtype, void* stream);
+
+/*
+ * out = x < 0 ? 0 : x over num_elements (a multiple of 8) contiguous 16-bit values; NaN and -0.0
+ * pass through.  The activation of an OPT-style MLP (fc1 -> ReLU -> fc2).  out may alias x.
+ */
+int32_t mi355_relu(void* out, const void* x, int64_t num_elements, int32_t dtype, void* stream);
+
+/*
  * Rotary embedding (NeoX / rotate-half pairing (i, i + head_dim/2)) applied in
  * place to the q and k parts of the packed QKV projection output, fused with the
  * paged KV-cache store of k (rotated) and v.

@@ -39,6 +39,18 @@ int32_t mi355_cpu_fused_add_rms_norm(void* out, const void* x, void* residual, c
                                      int64_t out_stride, int64_t residual_stride, float eps,
                                      int32_t dtype);
 
+/* twin of mi355_layer_norm */
+int32_t mi355_cpu_layer_norm(void* out, const void* x, const void* weight, const void* bias, int64_t num_tokens,
+                             int32_t hidden, int64_t x_stride, int64_t out_stride, float eps, int32_t dtype);
+
+/* twin of mi355_fused_add_layer_norm */
+int32_t mi355_cpu_fused_add_layer_norm(void* out, const void* x, void* residual, const void* weight,
+                                       const void* bias, int64_t num_tokens, int32_t hidden, int64_t x_stride,
+                                       int64_t out_stride, int64_t residual_stride, float eps, int32_t dtype);
+
+/* twin of mi355_relu */
+int32_t mi355_cpu_relu(void* out, const void* x, int64_t num_elements, int32_t dtype);
+
 /* twin of mi355_rope_kv_write */
 int32_t mi355_cpu_rope_kv_write(void* qkv, int64_t qkv_stride, const int64_t* positions,
                                 const void* cos_sin, int32_t max_position,

@@ -11,6 +11,8 @@ Three groups of fixtures:
                         functions (LlamaRMSNorm, LlamaRotaryEmbedding +
                         apply_rotary_pos_emb, eager_attention_forward, the MLP
                         activation, torch.argmax)
+  ops_opt_hf.npz        the operators OPT adds: torch.nn.LayerNorm (+ residual add), ReLU, the
+                        embedding + OPTLearnedPositionalEmbedding sum
   tiny_<model>.npz      greedy generations + logits of seeded tiny checkpoints
                         (oracle/tiny_models.py) run by HF in fp32 and bf16
   harness_launch.json   container args / env / resources / labels produced by
@@ -150,6 +152,55 @@ def gen_ops():
 
 
 # --------------------------------------------------------------------------- #
+def gen_ops_opt():
+    """Operators OPT adds: torch.nn.LayerNorm (what HF modeling_opt.py builds its norms from), the
+    residual add before it, ReLU, and the embedding + learned-position sum -> ops_opt_hf.npz."""
+    import torch
+    from transformers import OPTConfig
+    from transformers.models.opt import modeling_opt as MO
+
+    rng = np.random.Generator(np.random.PCG64(2025))
+    out = {}
+
+    def grid(shape, scale=1.0):
+        return round_to((rng.standard_normal(shape) * scale).astype(np.float32), "bfloat16")
+
+    for tag, (T, H) in {"a": (5, 384), "b": (3, 768), "c": (2, 4096)}.items():
+        x, res = grid((T, H), 2.0), grid((T, H))
+        x[0] += 3.0                                    # a row with a clear non-zero mean
+        x = round_to(x, "bfloat16")
+        w = round_to(1.0 + 0.1 * rng.standard_normal(H).astype(np.float32), "bfloat16")
+        b = round_to(0.1 * rng.standard_normal(H).astype(np.float32), "bfloat16")
+        out[f"ln_{tag}_x"], out[f"ln_{tag}_res"], out[f"ln_{tag}_w"], out[f"ln_{tag}_b"] = x, res, w, b
+        for dt, tdt in (("bfloat16", torch.bfloat16), ("float32", torch.float32)):
+            m = torch.nn.LayerNorm(H)
+            m.weight.data, m.bias.data = torch.from_numpy(w), torch.from_numpy(b)
+            m = m.to(tdt)
+            xt, rt = torch.from_numpy(x).to(tdt), torch.from_numpy(res).to(tdt)
+            out[f"ln_{tag}_y_{dt}"] = f32(m(xt))
+            z = rt + xt
+            out[f"ln_{tag}_z_{dt}"] = f32(z)
+            out[f"ln_{tag}_yz_{dt}"] = f32(m(z))
+    x = grid((4, 512), 3.0)
+    x[0, 0], x[0, 1] = 0.0, -0.0
+    out["relu_x"], out["relu_y"] = x, f32(torch.relu(torch.from_numpy(x).to(torch.bfloat16)))
+    # embedding + learned positions through the HF module (offset 2)
+    V, H, P = 64, 128, 32
+    emb = MO.OPTLearnedPositionalEmbedding(P, H)
+    pw, ew = grid((P + 2, H), 0.5), grid((V, H))
+    emb.weight.data = torch.from_numpy(pw)
+    ids = rng.integers(0, V, size=(1, 9))
+    pos = np.arange(9, dtype=np.int64)[None]
+    out["pos_table"], out["pos_embed"], out["pos_ids"], out["pos_positions"] = pw, ew, ids[0], pos[0]
+    for dt, tdt in (("bfloat16", torch.bfloat16), ("float32", torch.float32)):
+        e = torch.from_numpy(ew).to(tdt)[torch.from_numpy(ids)]
+        pe = emb.to(tdt)(torch.ones(1, 9, dtype=torch.long), position_ids=torch.from_numpy(pos))
+        out[f"pos_sum_{dt}"] = f32((e + pe)[0])
+    np.savez_compressed(os.path.join(GOLD, "ops_opt_hf.npz"), **out)
+    print("ops_opt_hf.npz:", len(out), "arrays")
+
+
+# --------------------------------------------------------------------------- #
 def gen_tiny(only=None):
     import torch
     import transformers
@@ -161,10 +212,15 @@ def gen_tiny(only=None):
             continue
         arch, cfg, w = make_weights(name)
         cfg_cls = {"LlamaForCausalLM": transformers.LlamaConfig,
-                   "Qwen2ForCausalLM": transformers.Qwen2Config}[arch]
+                   "Qwen2ForCausalLM": transformers.Qwen2Config,
+                   "OPTForCausalLM": transformers.OPTConfig}[arch]
         model_cls = getattr(transformers, arch)
-        hf_cfg = cfg_cls(**{k: v for k, v in cfg.items() if k != "attention_bias"},
-                         **({"attention_bias": cfg["attention_bias"]} if arch == "LlamaForCausalLM" else {}))
+        if arch == "OPTForCausalLM":
+            hf_cfg = cfg_cls(**cfg, dropout=0.0, attention_dropout=0.0, layerdrop=0.0)
+            w = dict(w, **{"lm_head.weight": w["model.decoder.embed_tokens.weight"]})     # tied
+        else:
+            hf_cfg = cfg_cls(**{k: v for k, v in cfg.items() if k != "attention_bias"},
+                             **({"attention_bias": cfg["attention_bias"]} if arch == "LlamaForCausalLM" else {}))
         hf_cfg._attn_implementation = "eager"
         prompts = make_prompts(name, len(lengths), lengths)
         rec = {"lengths": np.array(lengths, dtype=np.int32), "gen_len": np.int32(G)}
@@ -343,6 +399,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["ops", "tiny", "harness"]
     if "ops" in which:
         gen_ops()
+    if "ops_opt" in which:
+        gen_ops_opt()
     if "tiny" in which:
         gen_tiny()
     only = [a.split("=", 1)[1] for a in which if a.startswith("tiny=")]   # e.g. tiny=qwen2_d128

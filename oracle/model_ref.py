@@ -1,5 +1,5 @@
-"""CPU restatement (numpy) of one engine step for Llama / Qwen2 style decoders
-over the paged KV cache.  TEST INFRASTRUCTURE (see oracle/__init__.py).
+"""CPU restatement (numpy) of one engine step for Llama / Qwen2 style decoders (RefModel) and
+for OPT (RefOPT) over the paged KV cache.  TEST INFRASTRUCTURE (see oracle/__init__.py).
 
 Follows HF transformers 5.15.0 models/llama/modeling_llama.py:
 LlamaDecoderLayer.forward (:295-326), LlamaAttention.forward (:243-281),
@@ -113,7 +113,89 @@ class RefModel:
         return x.astype(np.float32) @ lm.astype(np.float32).T
 
 
-def greedy_generate(model: RefModel, prompts, max_new_tokens: int):
+class RefOPT:
+    """OPT decoder (pre-LayerNorm form: do_layer_norm_before, as opt-125m / 1.3b / ... 175b) over
+    the same paged KV cache and with the same forward() signature as RefModel.
+
+    Follows HF transformers 5.15.0 models/opt/modeling_opt.py: OPTDecoderLayer.forward (:203-262:
+    LayerNorm -> attention -> residual add -> LayerNorm -> fc1 -> ReLU -> fc2 -> residual add),
+    OPTAttention.forward (:135-181: biased q/k/v/out projections; HF multiplies q by head_dim^-0.5
+    and rounds it before QK^T, the engine this replaces applies the same factor to the fp32 scores
+    inside its attention kernel -- done here as the engine does; for head_dim 64 the factor is
+    0.125 and the two are the same numbers), OPTLearnedPositionalEmbedding (:44-70, offset 2),
+    OPTDecoder.forward (embeddings + positions, final_layer_norm) and OPTForCausalLM (lm_head tied to
+    the embeddings).  Pinned by tests/golden/tiny_opt_*.npz."""
+
+    POS_OFFSET = 2
+
+    def __init__(self, cfg: dict, weights: dict, dtype: str, num_blocks: int, block_size: int = 16,
+                 layers: int | None = None):
+        self.cfg, self.w, self.dtype, self.block_size = cfg, weights, dtype, block_size
+        self.H, self.nh = cfg["hidden_size"], cfg["num_attention_heads"]
+        self.d = self.H // self.nh
+        if cfg.get("word_embed_proj_dim", self.H) != self.H or not cfg.get("do_layer_norm_before", True):
+            raise ValueError("only the pre-LayerNorm OPT form without embedding projections is restated")
+        self.L = layers if layers is not None else cfg["num_hidden_layers"]
+        self.k_cache = [np.zeros((num_blocks, self.nh, block_size, self.d), np.float32) for _ in range(self.L)]
+        self.v_cache = [np.zeros((num_blocks, self.nh, self.d, block_size), np.float32) for _ in range(self.L)]
+        self.scale = 1.0 / np.sqrt(self.d)
+        self.eps = 1e-5
+        self._fused = {}
+
+    def _qkv(self, i):
+        if i not in self._fused:
+            p = f"model.decoder.layers.{i}.self_attn."
+            self._fused[i] = (np.concatenate([self.w[p + f"{n}_proj.weight"] for n in "qkv"], axis=0),
+                              np.concatenate([self.w[p + f"{n}_proj.bias"] for n in "qkv"], axis=0))
+        return self._fused[i]
+
+    def forward(self, token_ids, positions, slot_mapping, block_tables, context_lens,
+                cu_seqlens=None, logits_rows=None):
+        dt, nh, d, w = self.dtype, self.nh, self.d, self.w
+        D = "model.decoder."
+        h = R.embed_positions(w[D + "embed_tokens.weight"], w[D + "embed_positions.weight"], token_ids, positions,
+                              self.POS_OFFSET, dt)
+        T = h.shape[0]
+        residual = None
+        for i in range(self.L):
+            p = f"{D}layers.{i}."
+            wqkv, bqkv = self._qkv(i)
+            ln1 = (w[p + "self_attn_layer_norm.weight"], w[p + "self_attn_layer_norm.bias"])
+            if residual is None:
+                residual = h
+                x = R.layer_norm(h, *ln1, self.eps, dt)
+            else:
+                x, residual = R.fused_add_layer_norm(h, residual, *ln1, self.eps, dt)
+            qkv = R.linear(x, wqkv, bqkv, dt)
+            q = qkv[:, :nh * d].reshape(T, nh, d)
+            R.kv_write(qkv[:, nh * d:2 * nh * d].reshape(T, nh, d), qkv[:, 2 * nh * d:].reshape(T, nh, d),
+                       slot_mapping, self.k_cache[i], self.v_cache[i])
+            if cu_seqlens is None:
+                a = R.paged_attn_decode(q, self.k_cache[i], self.v_cache[i], block_tables, context_lens,
+                                        self.scale, dt)
+            else:
+                a = R.paged_attn_prefill(q, self.k_cache[i], self.v_cache[i], block_tables, cu_seqlens,
+                                         context_lens, self.scale, dt)
+            h = R.linear(a.reshape(T, nh * d), w[p + "self_attn.out_proj.weight"], w[p + "self_attn.out_proj.bias"], dt)
+            x, residual = R.fused_add_layer_norm(h, residual, w[p + "final_layer_norm.weight"],
+                                                 w[p + "final_layer_norm.bias"], self.eps, dt)
+            f1 = R.relu(R.linear(x, w[p + "fc1.weight"], w[p + "fc1.bias"], dt))
+            h = R.linear(f1, w[p + "fc2.weight"], w[p + "fc2.bias"], dt)
+        x, _ = R.fused_add_layer_norm(h, residual, w[D + "final_layer_norm.weight"], w[D + "final_layer_norm.bias"],
+                                      self.eps, dt)
+        if logits_rows is None:
+            logits_rows = np.arange(T) if cu_seqlens is None else np.asarray(cu_seqlens[1:], dtype=np.int64) - 1
+        return x[logits_rows].astype(np.float32) @ w[D + "embed_tokens.weight"].astype(np.float32).T
+
+
+def make_ref(arch: str, cfg: dict, weights: dict, dtype: str, num_blocks: int, **kw):
+    """The restatement of `arch` (an HF architecture name) over `weights`."""
+    if arch == "OPTForCausalLM":
+        return RefOPT(cfg, weights, dtype, num_blocks, **kw)
+    return RefModel(RefConfig(**cfg), weights, dtype, num_blocks, **kw)
+
+
+def greedy_generate(model, prompts, max_new_tokens: int):
     """Prefill all prompts in one packed step, then decode greedily.
     Block tables are assigned contiguously.  Returns (tokens [B, G], logits of
     every step as a list of [B, V] arrays)."""

@@ -96,11 +96,8 @@ def engine_generation():
     from mi355_decode.sampling_params import SamplingParams
     from oracle.tiny_models import make_prompts, make_weights
     out = []
-    for name in ("llama_d128", "qwen2_d64"):
-        try:
-            arch, cfg, w = make_weights(name)
-        except KeyError:
-            continue
+    for name in ("llama_d128", "qwen2_d64", "opt_d64"):
+        arch, cfg, w = make_weights(name)
         bounds.clear()
         eng = build_engine(EngineArgs(model=name, dtype="bfloat16", max_num_seqs=8, max_model_len=256,
                                       gpu_memory_utilization=0.0),

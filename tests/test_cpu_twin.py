@@ -38,6 +38,9 @@ def lib():
     sigs = {
         "mi355_cpu_rms_norm": [P, P, P, I64, I32, I64, I64, F, I32],
         "mi355_cpu_fused_add_rms_norm": [P, P, P, P, I64, I32, I64, I64, I64, F, I32],
+        "mi355_cpu_layer_norm": [P, P, P, P, I64, I32, I64, I64, F, I32],
+        "mi355_cpu_fused_add_layer_norm": [P, P, P, P, P, I64, I32, I64, I64, I64, F, I32],
+        "mi355_cpu_relu": [P, P, I64, I32],
         "mi355_cpu_rope_kv_write": [P, I64, P, P, I32, P, P, P, I32, I64, I32, I32, I32, I32],
         "mi355_cpu_paged_attn_decode": [P, P, I64, P, P, I32, P, I32, P, I32, I32, I32, I32, F, I32],
         "mi355_cpu_paged_attn_prefill": [P, I64, P, I64, P, P, I32, P, I32, P, P, I32, I32, I32, I32, I32, F, I32],
@@ -166,6 +169,32 @@ def test_norms_rope_silu_against_the_oracle(lib, dtype):
     xa, out = put(x, dtype), aligned(T * Fi)
     ok(lib, lib.mi355_cpu_silu_and_mul(out.ctypes.data, xa.ctypes.data, 2 * Fi, T, Fi, DT[dtype]))
     ulp_close(R.from_bits(out, dtype).reshape(T, Fi), R.silu_and_mul(x, dtype), dtype, 0.01)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_layer_norm_and_relu_against_the_oracle(lib, dtype):
+    rng = np.random.Generator(np.random.PCG64(6))
+    g = lambda *s, sc=1.0: R.round_to(rng.standard_normal(s).astype(np.float32) * sc, dtype)   # noqa: E731
+    T, H = 5, 768
+    x, res = g(T, H, sc=2.0), g(T, H)
+    x[0] = R.round_to(x[0] + 5.0, dtype)
+    w, b = R.round_to(1 + 0.1 * rng.standard_normal(H), dtype), R.round_to(0.1 * rng.standard_normal(H), dtype)
+    xa, wa, ba, ra, out = put(x, dtype), put(w, dtype), put(b, dtype), put(res, dtype), aligned(T * H)
+    ok(lib, lib.mi355_cpu_layer_norm(out.ctypes.data, xa.ctypes.data, wa.ctypes.data, ba.ctypes.data, T, H, H, H, 1e-5,
+                                     DT[dtype]))
+    ulp_close(R.from_bits(out, dtype).reshape(T, H), R.layer_norm(x, w, b, 1e-5, dtype), dtype, 0.005)
+    ok(lib, lib.mi355_cpu_fused_add_layer_norm(out.ctypes.data, xa.ctypes.data, ra.ctypes.data, wa.ctypes.data,
+                                               ba.ctypes.data, T, H, H, H, H, 1e-5, DT[dtype]))
+    y_ref, z_ref = R.fused_add_layer_norm(x, res, w, b, 1e-5, dtype)
+    np.testing.assert_array_equal(R.from_bits(ra, dtype).reshape(T, H), z_ref)            # residual add: bit-exact
+    ulp_close(R.from_bits(out, dtype).reshape(T, H), y_ref, dtype, 0.005)
+    v = g(64, sc=3.0)
+    v[:5] = [0.0, -0.0, np.inf, -np.inf, np.nan]
+    va, out = put(v, dtype), aligned(64)
+    ok(lib, lib.mi355_cpu_relu(out.ctypes.data, va.ctypes.data, 64, DT[dtype]))
+    np.testing.assert_array_equal(out, R.to_bits(R.relu(v), dtype))                       # bit-exact, -0.0 and NaN kept
+    assert lib.mi355_cpu_relu(out.ctypes.data, va.ctypes.data, 63, DT[dtype]) == -2
+    assert b"multiple of 8" in lib.mi355_cpu_last_error()
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])

@@ -50,7 +50,8 @@ def build(name, dtype, **kw):
 
 
 def oracle_run(cfg, w, dtype, prompts, gen):
-    model = M.RefModel(M.RefConfig(**cfg), w, dtype, num_blocks=len(prompts) * 8)
+    arch = "OPTForCausalLM" if "ffn_dim" in cfg else "LlamaForCausalLM"
+    model = M.make_ref(arch, cfg, w, dtype, num_blocks=len(prompts) * 8)
     return M.greedy_generate(model, prompts, gen)
 
 

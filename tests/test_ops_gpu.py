@@ -51,12 +51,14 @@ def host(t):
 SUBNORMAL_STEP = {"bfloat16": 2.0 ** -133, "float16": 2.0 ** -24}
 
 
-def assert_ulp_close(got, ref, dtype, max_frac):
+def assert_ulp_close(got, ref, dtype, max_frac, atol=0.0):
     """Equal except for rare flips: a one-ulp flip of the first rounding, scaled by
     the second factor and rounded again, moves the result by at most two ulps
-    (ulps of subnormal fp16 values are absolute: 2^-24)."""
+    (ulps of subnormal fp16 values are absolute: 2^-24).  `atol`: for results that are a
+    difference of larger terms (a norm's scaled value plus its bias), where the fp32 noise
+    of the terms, not an ulp of the small result, bounds the error."""
     diff = np.abs(got - ref)
-    tol = np.maximum(2 * ULP[dtype] * np.abs(ref) * 1.01, 2 * SUBNORMAL_STEP[dtype])
+    tol = np.maximum(np.maximum(2 * ULP[dtype] * np.abs(ref) * 1.01, 2 * SUBNORMAL_STEP[dtype]), atol)
     assert (diff <= tol).all(), f"max diff {diff.max()} (worst ref {ref.flat[diff.argmax()]})"
     frac = (diff > 0).mean()
     assert frac <= max_frac, f"{frac:.5f} of elements differ by one ulp (> {max_frac})"
@@ -97,6 +99,97 @@ def test_rms_norm_golden(ops, ops_golden):
         x, w, eps = g[f"rms_{tag}_x"], g[f"rms_{tag}_w"], float(g[f"rms_{tag}_eps"])
         y = ops.rms_norm(dev(x, "bfloat16"), dev(w, "bfloat16"), eps)
         assert_ulp_close(host(y), g[f"rms_{tag}_y_bfloat16"], "bfloat16", 0.005)
+
+
+# --------------------------------------------------------------------------- #
+# LayerNorm family (OPT): identical to the oracle up to single-ulp flips of the one final rounding
+# on a small fraction of elements (fp32 reduction order); the residual add and the embedding +
+# position sum are bit-exact.
+LN_ATOL = 2e-6      # normalised values of a few units x fp32 epsilon: where weight * value and bias cancel
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("T,H", [(1, 384), (5, 768), (32, 4096), (3, 8192), (2, 12288), (130, 1024)])
+def test_layer_norm(ops, dtype, T, H):
+    rng = rng_for("ln", dtype, T, H)
+    x, res = grid(rng, (T, H), dtype, 2.0), grid(rng, (T, H), dtype)
+    x[0] = R.round_to(x[0] + 5.0, dtype)                        # a row with a large mean
+    w = R.round_to(1 + 0.1 * rng.standard_normal(H), dtype)
+    b = R.round_to(0.1 * rng.standard_normal(H), dtype)
+    eps = 1e-5
+    y = ops.layer_norm(dev(x, dtype), dev(w, dtype), dev(b, dtype), eps)
+    assert_ulp_close(host(y), R.layer_norm(x, w, b, eps, dtype), dtype, 0.005, atol=LN_ATOL)
+
+    xd, rd = dev(x, dtype), dev(res, dtype)
+    out = ops.fused_add_layer_norm(xd, rd, dev(w, dtype), dev(b, dtype), eps)
+    y_ref, z_ref = R.fused_add_layer_norm(x, res, w, b, eps, dtype)
+    np.testing.assert_array_equal(host(rd), z_ref)            # residual add: bit-exact
+    assert out.data_ptr() == xd.data_ptr()                     # in place by default
+    assert_ulp_close(host(out), y_ref, dtype, 0.005, atol=LN_ATOL)
+
+
+def test_layer_norm_golden(ops):
+    from conftest import load_npz
+    g = load_npz("ops_opt_hf.npz")
+    for tag in "abc":
+        x, res, w, b = (g[f"ln_{tag}_{k}"] for k in ("x", "res", "w", "b"))
+        y = ops.layer_norm(dev(x, "bfloat16"), dev(w, "bfloat16"), dev(b, "bfloat16"), 1e-5)
+        assert_ulp_close(host(y), g[f"ln_{tag}_y_bfloat16"], "bfloat16", 0.005, atol=LN_ATOL)
+        xd, rd = dev(x, "bfloat16"), dev(res, "bfloat16")
+        ops.fused_add_layer_norm(xd, rd, dev(w, "bfloat16"), dev(b, "bfloat16"), 1e-5)
+        np.testing.assert_array_equal(host(rd), g[f"ln_{tag}_z_bfloat16"])
+        assert_ulp_close(host(xd), g[f"ln_{tag}_yz_bfloat16"], "bfloat16", 0.005, atol=LN_ATOL)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_embed_pos_layer_norm(ops, dtype):
+    rng = rng_for("embed-pos", dtype)
+    V, P, H, T = 320, 64, 768, 37
+    emb, pos_tab = grid(rng, (V, H), dtype), grid(rng, (P + 2, H), dtype, 0.5)
+    w = R.round_to(1 + 0.1 * rng.standard_normal(H), dtype)
+    b = R.round_to(0.1 * rng.standard_normal(H), dtype)
+    ids, pos = rng.integers(0, V, T), rng.integers(0, P, T)
+    resid = torch.empty(T, H, dtype=DT[dtype], device="cuda")
+    out = torch.empty_like(resid)
+    ops.embed_pos_layer_norm(dev(emb, dtype), torch.from_numpy(ids).cuda(), dev(pos_tab, dtype),
+                             torch.from_numpy(pos).cuda(), 2, dev(w, dtype), dev(b, dtype), 1e-5, resid, out)
+    want = R.embed_positions(emb, pos_tab, ids, pos, 2, dtype)
+    np.testing.assert_array_equal(host(resid), want)          # gather + add: bit-exact
+    assert_ulp_close(host(out), R.layer_norm(want, w, b, 1e-5, dtype), dtype, 0.005, atol=LN_ATOL)
+    # ids / positions outside their tables: row 0 / the nearest row, nothing faults
+    bad_ids, bad_pos = torch.tensor([-1, V, 5], device="cuda"), torch.tensor([0, 1, 10 ** 9], device="cuda")
+    r3, o3 = torch.empty(3, H, dtype=DT[dtype], device="cuda"), torch.empty(3, H, dtype=DT[dtype], device="cuda")
+    ops.embed_pos_layer_norm(dev(emb, dtype), bad_ids, dev(pos_tab, dtype), bad_pos, 2, dev(w, dtype), dev(b, dtype),
+                             1e-5, r3, o3)
+    np.testing.assert_array_equal(host(r3), R.embed_positions(emb, pos_tab, [0, 0, 5], [0, 1, P - 1], 2, dtype))
+
+
+def test_embed_pos_golden(ops):
+    from conftest import load_npz
+    g = load_npz("ops_opt_hf.npz")
+    H = g["pos_embed"].shape[1]
+    T = len(g["pos_ids"])
+    resid = torch.empty(T, H, dtype=torch.bfloat16, device="cuda")
+    ones, zeros = torch.ones(H, dtype=torch.bfloat16, device="cuda"), torch.zeros(H, dtype=torch.bfloat16, device="cuda")
+    ops.embed_pos_layer_norm(dev(g["pos_embed"], "bfloat16"), torch.from_numpy(g["pos_ids"]).cuda(),
+                             dev(g["pos_table"], "bfloat16"), torch.from_numpy(g["pos_positions"]).cuda(), 2, ones, zeros,
+                             1e-5, resid, torch.empty_like(resid))
+    np.testing.assert_array_equal(host(resid), g["pos_sum_bfloat16"])
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_relu(ops, dtype):
+    rng = rng_for("relu", dtype)
+    x = grid(rng, (33, 1024), dtype, 3.0)
+    x[0, :4] = [0.0, -0.0, np.inf, -np.inf]
+    x[1, 0] = np.nan
+    xd = dev(x, dtype)
+    y = ops.relu(xd)
+    assert y.data_ptr() == xd.data_ptr()
+    np.testing.assert_array_equal(R.to_bits(host(y), dtype), R.to_bits(R.relu(x), dtype))   # bit-exact, -0.0 and NaN included
+    from mi355_decode._lib import Mi355Error
+    with pytest.raises(Mi355Error, match="multiple of 8"):
+        ops.relu(torch.zeros(7, dtype=DT[dtype], device="cuda"))
 
 
 def test_rejects_bad_arguments(ops):

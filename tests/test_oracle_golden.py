@@ -36,6 +36,29 @@ def test_rms_norm(ops_golden, tag, dtype):
     close_dtype(y, g[f"rms_{tag}_yz_{dtype}"], dtype)
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("dtype", ["bfloat16", "float32"])
+def test_layer_norm(tag, dtype):
+    """torch.nn.LayerNorm (the norm of HF's OPT layers), alone and after the residual add."""
+    g = load_npz("ops_opt_hf.npz")
+    x, res, w, b = (g[f"ln_{tag}_{k}"] for k in ("x", "res", "w", "b"))
+    close_dtype(R.layer_norm(x, w, b, 1e-5, dtype), g[f"ln_{tag}_y_{dtype}"], dtype)
+    y, z = R.fused_add_layer_norm(x, res, w, b, 1e-5, dtype)
+    np.testing.assert_array_equal(z, g[f"ln_{tag}_z_{dtype}"])
+    close_dtype(y, g[f"ln_{tag}_yz_{dtype}"], dtype)
+
+
+def test_relu_and_learned_positions():
+    g = load_npz("ops_opt_hf.npz")
+    got = R.relu(g["relu_x"])
+    np.testing.assert_array_equal(got, g["relu_y"])
+    np.testing.assert_array_equal(np.signbit(got), np.signbit(g["relu_y"]))     # torch keeps -0.0
+    for dtype in ("bfloat16", "float32"):
+        np.testing.assert_array_equal(
+            R.embed_positions(g["pos_embed"], g["pos_table"], g["pos_ids"], g["pos_positions"], 2, dtype),
+            g[f"pos_sum_{dtype}"])
+
+
 @pytest.mark.parametrize("tag,d", [("d64", 64), ("d128", 128), ("q128", 128)])
 @pytest.mark.parametrize("dtype", ["bfloat16", "float32"])
 def test_rope(ops_golden, tag, d, dtype):
@@ -140,7 +163,7 @@ def _run_oracle(name, dtype, gen):
     prompts = make_prompts(name, len(lengths), lengths)
     for i, p in enumerate(prompts):
         np.testing.assert_array_equal(p, g[f"prompt{i}"])
-    model = M.RefModel(M.RefConfig(**cfg), w, dtype, num_blocks=len(prompts) * 8)
+    model = M.make_ref(arch, cfg, w, dtype, num_blocks=len(prompts) * 8)
     toks, logits = M.greedy_generate(model, prompts, gen)
     return g, toks, logits
 

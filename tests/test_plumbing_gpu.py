@@ -46,29 +46,35 @@ class ResultsStub(http.server.BaseHTTPRequestHandler):
         pass
 
 
-@pytest.mark.parametrize("case,tp", [("cfg2_llama3_8b_tp1", 1), ("cfg3_llama3_8b_tp4", 2)], ids=["tp1", "tp2_one_gpu"])
+@pytest.mark.parametrize("case,tp", [("cfg2_llama3_8b_tp1", 1), ("cfg3_llama3_8b_tp4", 2), ("cfg1_opt125m_cpu", 1)],
+                         ids=["tp1", "tp2_one_gpu", "opt125m_as_launched"])
 def test_harness_plumbing_pass(tmp_path, case, tp):
     """tp2_one_gpu: the tensor-parallel server as the harness launches it (--tensor-parallel-size from
     the TP config's args, cut to 2): rank 0 serves HTTP and starts the worker rank itself, requests
     reach the worker over the control channel, both step in lock-step exchanging partial sums -- the
-    two ranks share this box's one GPU and talk over gloo, which RCCL would not allow."""
+    two ranks share this box's one GPU and talk over gloo, which RCCL would not allow.
+    opt125m_as_launched: the args and env the harness generates when a request names no model
+    (facebook/opt-125m, --device cpu, --dtype float32, 2 sequences of 512 tokens), unchanged but for
+    host and port: the real OPT-125m geometry on seeded weights (nothing can be downloaded), served
+    by this engine's GPU path in bf16."""
     import torch
     assert torch.cuda.is_available()
     from mi355_decode.harness import BenchClient, evaluation_payload, result_pk
 
     launch = json.load(open(os.path.join(GOLDEN, "harness_launch.json")))
     args = list(launch["cases"][case]["deployment"]["args"])
-    args[args.index("--tensor-parallel-size") + 1] = str(tp)
-    args[args.index("--max-num-seqs") + 1] = "8"
-    model_dir = tmp_path / "tiny-llama"
-    model_dir.mkdir()
-    arch, cfg, _ = TINY["llama_d128"]
-    (model_dir / "config.json").write_text(json.dumps({**cfg, "architectures": [arch]}))
     port = free_port()
-    args[args.index("--model") + 1] = str(model_dir)
     args[args.index("--port") + 1] = str(port)
     args[args.index("--host") + 1] = "127.0.0.1"
-    args[args.index("--max-model-len") + 1] = "256"
+    if case != "cfg1_opt125m_cpu":
+        args[args.index("--tensor-parallel-size") + 1] = str(tp)
+        args[args.index("--max-num-seqs") + 1] = "8"
+        model_dir = tmp_path / "tiny-llama"
+        model_dir.mkdir()
+        arch, cfg, _ = TINY["llama_d128"]
+        (model_dir / "config.json").write_text(json.dumps({**cfg, "architectures": [arch]}))
+        args[args.index("--model") + 1] = str(model_dir)
+        args[args.index("--max-model-len") + 1] = "256"
     env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + ROOT)
     for e in launch["cases"][case]["deployment"]["env"]:     # the harness's env, CUDA_VISIBLE_DEVICES="" included
         env[e["name"]] = e["value"]

@@ -113,6 +113,35 @@ int32_t rms_norm_impl(uint16_t* out, const uint16_t* x, uint16_t* residual, cons
   return MI355_OK;
 }
 
+template <typename T>
+int32_t layer_norm_impl(uint16_t* out, const uint16_t* x, uint16_t* residual, const uint16_t* w, const uint16_t* b,
+                        int64_t T_, int hidden, int64_t xs, int64_t os, int64_t rs, float eps) {
+#pragma omp parallel for schedule(static)
+  for (int64_t t = 0; t < T_; ++t) {
+    std::vector<float> row(hidden);
+    float s = 0.f;
+    for (int j = 0; j < hidden; ++j) {
+      float f = T::to_f(x[t * xs + j]);
+      if (residual) {
+        f = rnd<T>(f + T::to_f(residual[t * rs + j]));
+        residual[t * rs + j] = T::from_f(f);
+      }
+      row[j] = f;
+      s += f;
+    }
+    const float mean = s / static_cast<float>(hidden);
+    float ss = 0.f;
+    for (int j = 0; j < hidden; ++j) ss += (row[j] - mean) * (row[j] - mean);
+    const float inv = 1.0f / sqrtf(ss / static_cast<float>(hidden) + eps);
+    for (int j = 0; j < hidden; ++j) {
+      const float n = (row[j] - mean) * inv;        // separate statements: no contraction across them with -ffp-contract=off
+      const float m = n * T::to_f(w[j]);
+      out[t * os + j] = T::from_f(m + T::to_f(b[j]));
+    }
+  }
+  return MI355_OK;
+}
+
 int32_t norm_checks(const char* name, const void* out, const void* x, const void* residual, bool add, const void* w,
                     int64_t T_, int32_t hidden, int64_t xs, int64_t os, int64_t rs, int32_t dtype) {
   CPU_REQUIRE(out && x && w && (!add || residual), MI355_ERR_INVALID, "%s: null pointer", name);
@@ -239,6 +268,55 @@ extern "C" int32_t mi355_cpu_fused_add_rms_norm(void* out, const void* x, void* 
   return dtype == MI355_BF16
              ? rms_norm_impl<BF16>(o, xi, r, w, num_tokens, hidden, x_stride, out_stride, residual_stride, eps)
              : rms_norm_impl<F16>(o, xi, r, w, num_tokens, hidden, x_stride, out_stride, residual_stride, eps);
+}
+
+extern "C" int32_t mi355_cpu_layer_norm(void* out, const void* x, const void* weight, const void* bias, int64_t num_tokens,
+                                        int32_t hidden, int64_t x_stride, int64_t out_stride, float eps, int32_t dtype) {
+  const char* name = "mi355_cpu_layer_norm";
+  const int32_t rc = norm_checks(name, out, x, nullptr, false, weight, num_tokens, hidden, x_stride, out_stride, 0, dtype);
+  if (rc != MI355_OK) return rc;
+  CPU_REQUIRE(bias && aligned16(bias), MI355_ERR_INVALID, "%s: bias missing or misaligned", name);
+  auto* o = static_cast<uint16_t*>(out);
+  auto* xi = static_cast<const uint16_t*>(x);
+  auto* w = static_cast<const uint16_t*>(weight);
+  auto* b = static_cast<const uint16_t*>(bias);
+  return dtype == MI355_BF16 ? layer_norm_impl<BF16>(o, xi, nullptr, w, b, num_tokens, hidden, x_stride, out_stride, 0, eps)
+                             : layer_norm_impl<F16>(o, xi, nullptr, w, b, num_tokens, hidden, x_stride, out_stride, 0, eps);
+}
+
+extern "C" int32_t mi355_cpu_fused_add_layer_norm(void* out, const void* x, void* residual, const void* weight,
+                                                  const void* bias, int64_t num_tokens, int32_t hidden, int64_t x_stride,
+                                                  int64_t out_stride, int64_t residual_stride, float eps, int32_t dtype) {
+  const char* name = "mi355_cpu_fused_add_layer_norm";
+  const int32_t rc = norm_checks(name, out, x, residual, true, weight, num_tokens, hidden, x_stride, out_stride,
+                                 residual_stride, dtype);
+  if (rc != MI355_OK) return rc;
+  CPU_REQUIRE(bias && aligned16(bias), MI355_ERR_INVALID, "%s: bias missing or misaligned", name);
+  auto* o = static_cast<uint16_t*>(out);
+  auto* xi = static_cast<const uint16_t*>(x);
+  auto* r = static_cast<uint16_t*>(residual);
+  auto* w = static_cast<const uint16_t*>(weight);
+  auto* b = static_cast<const uint16_t*>(bias);
+  return dtype == MI355_BF16
+             ? layer_norm_impl<BF16>(o, xi, r, w, b, num_tokens, hidden, x_stride, out_stride, residual_stride, eps)
+             : layer_norm_impl<F16>(o, xi, r, w, b, num_tokens, hidden, x_stride, out_stride, residual_stride, eps);
+}
+
+extern "C" int32_t mi355_cpu_relu(void* out, const void* x, int64_t num_elements, int32_t dtype) {
+  const char* name = "mi355_cpu_relu";
+  CPU_REQUIRE(out && x, MI355_ERR_INVALID, "%s: null pointer", name);
+  CPU_REQUIRE(num_elements >= 0 && num_elements % 8 == 0, MI355_ERR_UNSUPPORTED,
+              "%s: the element count %lld must be a non-negative multiple of 8", name, (long long)num_elements);
+  CPU_REQUIRE(aligned16(out) && aligned16(x), MI355_ERR_INVALID, "%s: pointers must be 16-byte aligned", name);
+  CPU_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED, "%s: dtype %d not supported (bf16/fp16 only)",
+              name, dtype);
+  auto* o = static_cast<uint16_t*>(out);
+  auto* xi = static_cast<const uint16_t*>(x);
+  for (int64_t i = 0; i < num_elements; ++i) {
+    const float f = dtype == MI355_BF16 ? BF16::to_f(xi[i]) : F16::to_f(xi[i]);
+    o[i] = f < 0.f ? static_cast<uint16_t>(0) : xi[i];       // NaN and -0.0 pass through
+  }
+  return MI355_OK;
 }
 
 template <typename T>

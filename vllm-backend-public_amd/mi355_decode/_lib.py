@@ -54,6 +54,11 @@ def _load() -> ctypes.CDLL:
         "mi355_argmax": (I32, [P, P, I64, I32, I32, I32, P]),
         "mi355_argmax_chunked": (I32, [P, P, P, P, I64, I32, I32, I32, P]),
         "mi355_embed_rms_norm": (I32, [P, P, P, P, I64, P, I64, I32, I64, I64, I64, F, I32, P]),
+        "mi355_layer_norm": (I32, [P, P, P, P, I64, I32, I64, I64, F, I32, P]),
+        "mi355_fused_add_layer_norm": (I32, [P, P, P, P, P, I64, I32, I64, I64, I64, F, I32, P]),
+        "mi355_embed_pos_layer_norm": (I32, [P, P, P, P, I64, I64, P, P, I64, I64, I64, P, P, I64, I32, I64, I64, F,
+                                             I32, P]),
+        "mi355_relu": (I32, [P, P, I64, I32, P]),
         "mi355_argmax_shard_key": (I32, [P, P, I64, I32, I32, I32, I64, P]),
         "mi355_argmax_key_to_index": (I32, [P, P, I32, P]),
         "mi355_tiled_weight_elems": (I64, [I32, I32]),
@@ -94,6 +99,7 @@ EXPORTS = ("mi355_abi_version", "mi355_last_error", "mi355_target_arch",
            "mi355_fused_add_rms_norm", "mi355_rope_kv_write", "mi355_paged_attn_decode_workspace",
            "mi355_paged_attn_decode", "mi355_paged_attn_decode_static", "mi355_paged_attn_prefill", "mi355_silu_and_mul", "mi355_argmax",
            "mi355_argmax_chunked", "mi355_embed_rms_norm",
+           "mi355_layer_norm", "mi355_fused_add_layer_norm", "mi355_embed_pos_layer_norm", "mi355_relu",
            "mi355_argmax_shard_key", "mi355_argmax_key_to_index",
            "mi355_linear_decode", "mi355_sample_topk_topp",
            "mi355_tiled_weight_elems", "mi355_tile_weights", "mi355_linear_tiled",

@@ -14,7 +14,7 @@ import os
 from dataclasses import dataclass, field
 from typing import Any, Optional
 
-SUPPORTED_ARCHS = ("LlamaForCausalLM", "Qwen2ForCausalLM", "MistralForCausalLM")
+SUPPORTED_ARCHS = ("LlamaForCausalLM", "Qwen2ForCausalLM", "MistralForCausalLM", "OPTForCausalLM")
 
 # Well-known geometries, used when --model names one of them and no local
 # config.json exists (synthetic-weight benchmarking; there is no network).
@@ -27,6 +27,11 @@ KNOWN_MODELS = {
                         intermediate_size=28672, num_hidden_layers=80, num_attention_heads=64,
                         num_key_value_heads=8, rope_theta=500000.0, rms_norm_eps=1e-5,
                         max_position_embeddings=8192, tie_word_embeddings=False),
+    # the model the harness launches when a request names none (benchmark-vllm/models.py:7)
+    "opt-125m": dict(architectures=["OPTForCausalLM"], vocab_size=50272, hidden_size=768, ffn_dim=3072,
+                     num_hidden_layers=12, num_attention_heads=12, max_position_embeddings=2048,
+                     word_embed_proj_dim=768, do_layer_norm_before=True, activation_function="relu",
+                     bos_token_id=2, eos_token_id=2),
     "qwen2-7b": dict(architectures=["Qwen2ForCausalLM"], vocab_size=152064, hidden_size=3584,
                      intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28,
                      num_key_value_heads=4, rope_theta=1000000.0, rms_norm_eps=1e-6,
@@ -60,6 +65,32 @@ class ModelConfig:
     attention_bias: bool
     bos_token_id: Optional[int] = None
     eos_token_id: Any = None
+    # the decoder family: "llama" (RMSNorm, rotary positions, SwiGLU MLP) or "opt" (LayerNorm with
+    # bias, learned positions stored at an offset, biased projections, fc1 -> ReLU -> fc2)
+    family: str = "llama"
+    position_offset: int = 0
+
+    @classmethod
+    def _from_opt_dict(cls, d: dict) -> "ModelConfig":
+        H, nh = d["hidden_size"], d["num_attention_heads"]
+        if d.get("word_embed_proj_dim", H) != H:
+            raise ValueError("OPT checkpoints whose embeddings are projected (word_embed_proj_dim != hidden_size, "
+                             "opt-350m) are not supported")
+        if not d.get("do_layer_norm_before", True):
+            raise ValueError("OPT checkpoints that normalise after the sub-layers (do_layer_norm_before false, "
+                             "opt-350m) are not supported")
+        if d.get("activation_function", "relu") != "relu" or not d.get("enable_bias", True) \
+                or not d.get("layer_norm_elementwise_affine", True):
+            raise ValueError("OPT variants without biases / affine norms or with another activation than ReLU are "
+                             "not supported")
+        return cls(architecture="OPTForCausalLM", vocab_size=d["vocab_size"], hidden_size=H,
+                   intermediate_size=d["ffn_dim"], num_hidden_layers=d["num_hidden_layers"], num_attention_heads=nh,
+                   num_key_value_heads=nh, head_dim=H // nh, rope_theta=0.0, rope_scaling=None,
+                   rms_norm_eps=1e-5,                     # torch.nn.LayerNorm's default, which OPT keeps
+                   max_position_embeddings=int(d.get("max_position_embeddings", 2048)),
+                   tie_word_embeddings=bool(d.get("tie_word_embeddings", True)), attention_bias=True,
+                   bos_token_id=d.get("bos_token_id"), eos_token_id=d.get("eos_token_id"), family="opt",
+                   position_offset=2)
 
     @classmethod
     def from_dict(cls, d: dict) -> "ModelConfig":
@@ -67,6 +98,8 @@ class ModelConfig:
         arch = archs[0]
         if arch not in SUPPORTED_ARCHS:
             raise ValueError(f"architecture {arch!r} is not supported (supported: {SUPPORTED_ARCHS})")
+        if arch == "OPTForCausalLM":
+            return cls._from_opt_dict(d)
         nh = d["num_attention_heads"]
         rope_params = d.get("rope_parameters") or {}
         rope_scaling = d.get("rope_scaling")
@@ -117,6 +150,9 @@ class ModelConfig:
         H, F, V, L = self.hidden_size, self.intermediate_size, self.vocab_size, self.num_hidden_layers
         qkv = (self.num_attention_heads + 2 * self.num_key_value_heads) * self.head_dim * H
         o = self.num_attention_heads * self.head_dim * H
+        if self.family == "opt":
+            per_layer = qkv + o + 2 * F * H + (qkv // H + 2 * H + F) + 4 * H
+            return L * per_layer + V * H + (self.max_position_embeddings + self.position_offset) * H + 2 * H
         per_layer = qkv + o + 3 * F * H + 2 * H
         return L * per_layer + V * H * (1 if self.tie_word_embeddings else 2) + H
 

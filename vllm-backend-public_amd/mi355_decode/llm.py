@@ -86,6 +86,10 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
         log.warning("--block-size %d requested: this engine always uses %d-token KV pages",
                     args.block_size, BLOCK_SIZE)
     max_model_len = args.max_model_len or min(cfg.max_position_embeddings, 8192)
+    if cfg.family == "opt" and max_model_len > cfg.max_position_embeddings:
+        log.warning("--max-model-len %d exceeds the model's %d learned positions: serving %d", max_model_len,
+                    cfg.max_position_embeddings, cfg.max_position_embeddings)
+        max_model_len = cfg.max_position_embeddings
     nl = args.num_layers_override
     tp = world if args.tensor_parallel_size > 1 else 1
     # MI355_TP_MLP=0 keeps the MLP replicated under tensor parallelism (one all-reduce per layer
@@ -106,15 +110,22 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
     # the runner keeps a second, fragment-tiled copy of the decode-time matrices (the o
     # projection only without tensor parallelism)
     fp8 = (args.quantization or "").lower() == "fp8"
-    tiled_bytes = sum(t.numel() * (1 if fp8 else t.element_size()) for lw in weights.layers
-                      for t in (lw.qkv_w, lw.gate_up_w) + ((lw.o_w,) if tp == 1 else ())
-                      + (() if shard_mlp else (lw.down_w,)))
-    tiled_bytes += weights.lm_head.numel() * weights.lm_head.element_size()
+    if cfg.family == "opt":
+        tiled_bytes = 0                               # its decode GEMMs stream the row-major weights
+    else:
+        tiled_bytes = sum(t.numel() * (1 if fp8 else t.element_size()) for lw in weights.layers
+                          for t in (lw.qkv_w, lw.gate_up_w) + ((lw.o_w,) if tp == 1 else ())
+                          + (() if shard_mlp else (lw.down_w,)))
+        tiled_bytes += weights.lm_head.numel() * weights.lm_head.element_size()
     num_blocks = plan_num_blocks(args, cfg, tp, len(weights.layers), max_model_len,
                                  torch.empty(0, dtype=dtype).element_size(), device, extra_reserve=tiled_bytes)
     # only RCCL collectives can be captured into the decode graph
     graphs = not args.enforce_eager and (tp == 1 or torch.distributed.get_backend(group) == "nccl")
-    runner = ModelRunner(cfg, weights, dtype, device, num_blocks, args.max_num_seqs, max_model_len,
+    runner_cls = ModelRunner
+    if cfg.family == "opt":
+        from .opt_runner import OPTRunner
+        runner_cls = OPTRunner
+    runner = runner_cls(cfg, weights, dtype, device, num_blocks, args.max_num_seqs, max_model_len,
                          tp_rank=rank, tp_size=tp, tp_group=group, use_graphs=graphs,
                          decode_splits=decode_splits, weight_fp8=(args.quantization or "").lower() == "fp8")
     if tp > 1 and os.environ.get("MI355_ONESHOT_ALLREDUCE", "0") == "1":

@@ -32,6 +32,10 @@ def build_cos_sin_table(cfg: ModelConfig, max_pos: int, dtype: torch.dtype, devi
     """[max_pos, head_dim] = cos | sin halves, computed in fp32 and rounded to the
     model dtype (the table a 16-bit model rotates with)."""
     d = cfg.head_dim
+    if cfg.family == "opt":
+        # learned positions: no rotation.  One row, cos = 1 | sin = 0 -- the kernels clamp every
+        # position to the table's last row, and rotating by it returns the input bit for bit
+        return torch.cat([torch.ones(1, d // 2), torch.zeros(1, d // 2)], dim=1).to(dtype).contiguous().to(device)
     inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.int64).float() / d))
     sc = cfg.rope_scaling
     if sc is not None:  # "llama3" frequency-dependent scaling

@@ -347,6 +347,79 @@ def embed_rms_norm(embed: torch.Tensor, token_ids: torch.Tensor, weight: torch.T
     return out
 
 
+def _affine(weight: torch.Tensor, bias: torch.Tensor, hidden: int, dtype) -> None:
+    for t, n in ((weight, "weight"), (bias, "bias")):
+        _dev(t, n)
+        if t.dtype != dtype or t.numel() != hidden or not t.is_contiguous():
+            raise ValueError(f"{n} must be contiguous [hidden] in the dtype of the rows")
+
+
+def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float,
+               out: torch.Tensor | None = None):
+    """LayerNorm with weight and bias over the rows of x (OPT-style decoders)."""
+    dt = _dt16(x, "x")
+    _affine(weight, bias, x.shape[1], x.dtype)
+    if out is None:
+        out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    check(lib.mi355_layer_norm(out.data_ptr(), x.data_ptr(), weight.data_ptr(), bias.data_ptr(), x.shape[0], x.shape[1],
+                               _rows(x, "x"), _rows(out, "out"), float(eps), dt, _stream()))
+    return out
+
+
+def fused_add_layer_norm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float,
+                         out: torch.Tensor | None = None):
+    """residual <- x + residual (in place); returns layer_norm(residual).  ``out`` defaults to ``x``."""
+    dt = _dt16(x, "x")
+    _dev(residual, "residual")
+    if residual.dtype != x.dtype or residual.shape != x.shape:
+        raise ValueError("residual must match x")
+    _affine(weight, bias, x.shape[1], x.dtype)
+    if out is None:
+        out = x
+    check(lib.mi355_fused_add_layer_norm(out.data_ptr(), x.data_ptr(), residual.data_ptr(), weight.data_ptr(),
+                                         bias.data_ptr(), x.shape[0], x.shape[1], _rows(x, "x"), _rows(out, "out"),
+                                         _rows(residual, "residual"), float(eps), dt, _stream()))
+    return out
+
+
+def embed_pos_layer_norm(embed: torch.Tensor, token_ids: torch.Tensor, pos_embed: torch.Tensor,
+                         positions: torch.Tensor, position_offset: int, weight: torch.Tensor, bias: torch.Tensor,
+                         eps: float, residual: torch.Tensor, out: torch.Tensor):
+    """residual <- embed[token_ids] + pos_embed[positions + position_offset]; out <- layer_norm(residual):
+    the first launch of an OPT-style step."""
+    dt = _dt16(embed, "embed")
+    _dev(token_ids, "token_ids"), _dev(positions, "positions"), _dev(residual, "residual"), _dev(out, "out")
+    _dev(pos_embed, "pos_embed")
+    T, H = token_ids.numel(), embed.shape[1]
+    for t, n in ((token_ids, "token_ids"), (positions, "positions")):
+        if t.dtype != torch.int64 or t.numel() != T or not t.is_contiguous():
+            raise ValueError(f"{n} must be contiguous int64 [num_tokens]")
+    if pos_embed.dtype != embed.dtype or pos_embed.dim() != 2 or pos_embed.shape[1] != H:
+        raise ValueError("pos_embed must be [num_positions, hidden] in the dtype of embed")
+    _affine(weight, bias, H, embed.dtype)
+    for t, n in ((residual, "residual"), (out, "out")):
+        if t.dtype != embed.dtype or tuple(t.shape) != (T, H):
+            raise ValueError(f"{n} must be [num_tokens, hidden] in the dtype of embed")
+    check(lib.mi355_embed_pos_layer_norm(out.data_ptr(), residual.data_ptr(), embed.data_ptr(), token_ids.data_ptr(),
+                                         embed.shape[0], _rows(embed, "embed"), pos_embed.data_ptr(),
+                                         positions.data_ptr(), pos_embed.shape[0], int(position_offset),
+                                         _rows(pos_embed, "pos_embed"), weight.data_ptr(), bias.data_ptr(), T, H,
+                                         _rows(out, "out"), _rows(residual, "residual"), float(eps), dt, _stream()))
+    return out
+
+
+def relu(x: torch.Tensor, out: torch.Tensor | None = None):
+    """x < 0 ? 0 : x (NaN and -0.0 kept); in place by default."""
+    dt = _dt16(x, "x")
+    if out is None:
+        out = x
+    _dev(out, "out")
+    if not x.is_contiguous() or not out.is_contiguous() or out.dtype != x.dtype or out.numel() != x.numel():
+        raise ValueError("x and out must be contiguous tensors of one size and dtype")
+    check(lib.mi355_relu(out.data_ptr(), x.data_ptr(), x.numel(), dt, _stream()))
+    return out
+
+
 def argmax_shard_key(logits: torch.Tensor, index_offset: int, out: torch.Tensor | None = None):
     """Key of the best token of a vocabulary slice whose first row is token `index_offset`:
     a signed 64-bit max over the slices' keys is the key of the argmax of the whole vocabulary

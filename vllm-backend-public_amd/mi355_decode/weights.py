@@ -42,20 +42,53 @@ class LayerWeights:
 
 
 @dataclass
+class OPTLayerWeights:
+    """One OPT decoder layer: q/k/v concatenated like LayerWeights; every projection has a bias,
+    both norms a weight and a bias."""
+    qkv_w: torch.Tensor
+    qkv_b: torch.Tensor
+    o_w: torch.Tensor
+    o_b: torch.Tensor
+    fc1_w: torch.Tensor
+    fc1_b: torch.Tensor
+    fc2_w: torch.Tensor
+    fc2_b: torch.Tensor
+    attn_norm_w: torch.Tensor
+    attn_norm_b: torch.Tensor
+    mlp_norm_w: torch.Tensor
+    mlp_norm_b: torch.Tensor
+
+    @property
+    def down_w(self) -> torch.Tensor:          # [hidden, intermediate], the name the runner sizes its buffers by
+        return self.fc2_w
+
+    def tensors(self):
+        return (self.qkv_w, self.qkv_b, self.o_w, self.o_b, self.fc1_w, self.fc1_b, self.fc2_w, self.fc2_b,
+                self.attn_norm_w, self.attn_norm_b, self.mlp_norm_w, self.mlp_norm_b)
+
+
+@dataclass
 class ModelWeights:
     embed: torch.Tensor
     layers: list = field(default_factory=list)
     final_norm: torch.Tensor = None
     lm_head: torch.Tensor = None
     synthetic: bool = False
+    pos_embed: Optional[torch.Tensor] = None     # learned positions (OPT): [max_positions + offset, hidden]
+    final_norm_b: Optional[torch.Tensor] = None
 
     def nbytes(self) -> int:
         total = self.embed.numel() * self.embed.element_size()
         if self.lm_head.untyped_storage().data_ptr() != self.embed.untyped_storage().data_ptr():
             total += self.lm_head.numel() * self.lm_head.element_size()
         total += self.final_norm.numel() * self.final_norm.element_size()
+        for t in (self.pos_embed, self.final_norm_b):
+            if t is not None:
+                total += t.numel() * t.element_size()
         for lw in self.layers:
-            for t in (lw.qkv_w, lw.qkv_b, lw.o_w, lw.gate_up_w, lw.down_w, lw.input_norm, lw.post_norm):
+            ts = lw.tensors() if isinstance(lw, OPTLayerWeights) else \
+                (lw.qkv_w, lw.qkv_b, lw.o_w, lw.gate_up_w, lw.down_w, lw.input_norm, lw.post_norm)
+            for t in ts:
                 if t is not None:
                     total += t.numel() * t.element_size()
         return total
@@ -89,6 +122,8 @@ def from_getter(cfg: ModelConfig, get: Callable[[str], torch.Tensor], dtype: tor
                 tp_rank: int = 0, tp_size: int = 1, num_layers: Optional[int] = None,
                 shard_mlp: bool = False, shard_vocab: bool = False) -> ModelWeights:
     """``get(name)`` returns the full (unsharded) CPU tensor of an HF parameter."""
+    if cfg.family == "opt":
+        return _opt_from_getter(cfg, get, dtype, device, tp_size, num_layers)
     _, _, qs, ks = _shard_heads(cfg, tp_rank, tp_size)
     fs = _shard_mlp(cfg, tp_rank, tp_size) if shard_mlp else slice(None)
 
@@ -115,6 +150,63 @@ def from_getter(cfg: ModelConfig, get: Callable[[str], torch.Tensor], dtype: tor
     w.final_norm = put(get("model.norm.weight"))
     vs = _shard_vocab(cfg, tp_rank, tp_size) if shard_vocab else slice(None)
     w.lm_head = w.embed[vs] if cfg.tie_word_embeddings else put(get("lm_head.weight")[vs])
+    return w
+
+
+def _opt_only_one_gpu(tp_size: int) -> None:
+    if tp_size != 1:
+        raise ValueError("OPT models run on one GPU (tensor_parallel_size 1): the harness deploys them as its "
+                         "single-process plumbing case")
+
+
+def _opt_from_getter(cfg: ModelConfig, get, dtype, device, tp_size: int, num_layers: Optional[int]) -> ModelWeights:
+    """HF OPT parameter names (model.decoder.*; transformers models/opt/modeling_opt.py)."""
+    _opt_only_one_gpu(tp_size)
+
+    def put(t: torch.Tensor) -> torch.Tensor:
+        return t.to(dtype).contiguous().to(device)
+
+    D = "model.decoder."
+    L = num_layers if num_layers is not None else cfg.num_hidden_layers
+    w = ModelWeights(embed=put(get(D + "embed_tokens.weight")), pos_embed=put(get(D + "embed_positions.weight")))
+    for i in range(L):
+        p = f"{D}layers.{i}."
+        w.layers.append(OPTLayerWeights(
+            qkv_w=put(torch.cat([get(p + f"self_attn.{n}_proj.weight") for n in "qkv"], dim=0)),
+            qkv_b=put(torch.cat([get(p + f"self_attn.{n}_proj.bias") for n in "qkv"], dim=0)),
+            o_w=put(get(p + "self_attn.out_proj.weight")), o_b=put(get(p + "self_attn.out_proj.bias")),
+            fc1_w=put(get(p + "fc1.weight")), fc1_b=put(get(p + "fc1.bias")),
+            fc2_w=put(get(p + "fc2.weight")), fc2_b=put(get(p + "fc2.bias")),
+            attn_norm_w=put(get(p + "self_attn_layer_norm.weight")), attn_norm_b=put(get(p + "self_attn_layer_norm.bias")),
+            mlp_norm_w=put(get(p + "final_layer_norm.weight")), mlp_norm_b=put(get(p + "final_layer_norm.bias"))))
+    w.final_norm = put(get(D + "final_layer_norm.weight"))
+    w.final_norm_b = put(get(D + "final_layer_norm.bias"))
+    w.lm_head = w.embed                                  # tied (OPTForCausalLM ties lm_head to embed_tokens)
+    return w
+
+
+def _opt_synthetic(cfg: ModelConfig, dtype, device, seed: int, tp_size: int, num_layers: Optional[int],
+                   std: float) -> ModelWeights:
+    _opt_only_one_gpu(tp_size)
+    H, F, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+    gen = torch.Generator(device=device).manual_seed(seed)
+
+    def mat(*shape):
+        return torch.empty(shape, dtype=dtype, device=device).normal_(0.0, std, generator=gen)
+
+    def ones():
+        return torch.ones(H, dtype=dtype, device=device)
+
+    L = num_layers if num_layers is not None else cfg.num_hidden_layers
+    w = ModelWeights(embed=mat(V, H), synthetic=True,
+                     pos_embed=mat(cfg.max_position_embeddings + cfg.position_offset, H))
+    for _ in range(L):
+        w.layers.append(OPTLayerWeights(
+            qkv_w=mat(3 * H, H), qkv_b=mat(3 * H), o_w=mat(H, H), o_b=mat(H), fc1_w=mat(F, H), fc1_b=mat(F),
+            fc2_w=mat(H, F), fc2_b=mat(H), attn_norm_w=ones(), attn_norm_b=mat(H), mlp_norm_w=ones(),
+            mlp_norm_b=mat(H)))
+    w.final_norm, w.final_norm_b = ones(), mat(H)
+    w.lm_head = w.embed
     return w
 
 
@@ -162,6 +254,8 @@ def synthetic(cfg: ModelConfig, dtype, device, seed: int = 0, tp_rank: int = 0, 
     """Seeded N(0, std^2) matrices of the real shapes, generated on the device
     (an 8B model is 15 GB: too slow to draw on the host).  Every rank draws the
     replicated tensors from the same stream so they are bit-identical across ranks."""
+    if cfg.family == "opt":
+        return _opt_synthetic(cfg, dtype, device, seed, tp_size, num_layers, std)
     nh_l, nkv_l, _, _ = _shard_heads(cfg, tp_rank, tp_size)
     H, F, V, d = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.head_dim
     if shard_mlp:
