@@ -645,6 +645,57 @@ def test_linear_tiled_store(ops, dtype, M, N, K, bias, tiles):
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,N,K,bias", [(16, 1280, 8192, False), (32, 8192, 1024, True), (5, 320, 1024, True),
+                                        (17, 1000, 2048, False), (1, 16, 1024, False), (32, 4096, 4096, True)])
+@pytest.mark.parametrize("tiles", [302, 304, 308, 402, 404])
+def test_linear_tiled_k_split_across_waves(ops, dtype, M, N, K, bias, tiles):
+    """The narrow-slice geometries (the shapes of a tensor-parallel rank's qkv / o projection among them):
+    store epilogue against the oracle, partial-sum slabs against float64 products of their K ranges."""
+    rng = rng_for("tiled-kw", dtype, M, N, K)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (N, K), dtype, 0.05)
+    b = grid(rng, (N,), dtype) if bias else None
+    wt = ops.tile_weights(dev(w, dtype))
+    y = host(ops.linear_tiled(dev(x, dtype), wt, N, dev(b, dtype) if bias else None, tiles_per_wg=tiles))
+    ref64 = x.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
+    err = np.abs(y - ref64)
+    assert (err <= _linear_tol(ref64, x, w, K, dtype)).all(), f"max err {err.max()}"
+    assert (y != R.linear(x, w, b, dtype)).mean() <= 0.02
+    unit = ops.tiled_slice_width(M, tiles)
+    for groups in {1, min(2, K // unit), min(4, K // unit)}:
+        part = ops.linear_tiled(dev(x, dtype), wt, N, k_groups=groups, epilogue=ops.EPI_PARTIAL, tiles_per_wg=tiles)
+        part = part.cpu().numpy()
+        assert part.shape == (groups, M, N)
+        units = K // unit
+        start = 0
+        for g in range(groups):                  # slices dealt as evenly as they go, the first groups one more
+            n = units // groups + (1 if g < units % groups else 0)
+            a, e = start * unit, (start + n) * unit
+            start += n
+            ref = x[:, a:e].astype(np.float64) @ w[:, a:e].astype(np.float64).T
+            np.testing.assert_allclose(part[g], ref, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,F,K", [(16, 3584, 8192), (7, 512, 1024), (32, 1536, 1024), (1, 64, 2048)])
+@pytest.mark.parametrize("tiles", [302, 304, 402, 404])
+def test_linear_tiled_k_split_across_waves_swiglu(ops, dtype, M, F, K, tiles):
+    rng = rng_for("tiled-kw-silu", dtype, M, F, K)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (2 * F, K), dtype, 0.05)
+    wt = ops.tile_weights(dev(w, dtype), interleave_halves=True)
+    y = host(ops.linear_tiled(dev(x, dtype), wt, 2 * F, epilogue=ops.EPI_SILU_MUL, tiles_per_wg=tiles))
+    ref = R.silu_and_mul(R.linear(x, w, None, dtype), dtype)
+    diff = np.abs(y - ref)
+    assert (diff <= 4 * ULP[dtype] * np.abs(ref) + 4 * ULP[dtype] * 1e-2).all(), f"max diff {diff.max()}"
+    assert (diff > 0).mean() <= 0.03
+    # the gate on the same sums, unfused
+    gu = ops.linear_tiled(dev(x, dtype), ops.tile_weights(dev(w, dtype)), 2 * F, tiles_per_wg=tiles)
+    np.testing.assert_array_equal(y, host(ops.silu_and_mul(gu)))
+    from mi355_decode._lib import Mi355Error
+    with pytest.raises(Mi355Error, match="at most 4 waves per tile"):
+        ops.linear_tiled(dev(x, dtype), wt, 2 * F, epilogue=ops.EPI_SILU_MUL, tiles_per_wg=308)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 @pytest.mark.parametrize("M,N,K,groups", [(32, 4096, 4096, 4), (32, 4096, 14336, 7), (9, 512, 2048, 2), (32, 256, 1024, 1)])
 def test_linear_tiled_partial_slabs(ops, dtype, M, N, K, groups):
     rng = rng_for("tiled-partial", dtype, M, N, K)

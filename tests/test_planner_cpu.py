@@ -10,7 +10,8 @@ SHAPES = [  # N, K, split_k: the projections of the benchmark models and of thei
     (4608, 3584, True), (3584, 3584, True), (37888, 3584, False), (3584, 18944, True), (152064, 3584, False),
     (1280, 8192, True), (8192, 1024, True), (7168, 8192, False), (16032, 4096, False), (1536, 4096, True),
 ]
-BUILT = {16: {4, 8, 104, 108}, 32: {4, 8, 104, 108}, 64: {8, 104, 108, 208, 216}, 128: {8, 216}}
+KW = {302, 304, 308, 402, 404}        # K split across the waves of a workgroup: up to 32 rows
+BUILT = {16: {4, 8, 104, 108} | KW, 32: {4, 8, 104, 108} | KW, 64: {8, 104, 108, 208, 216}, 128: {8, 216}}
 
 
 @pytest.mark.parametrize("M", [1, 16, 17, 32, 33, 64, 65, 128])
@@ -28,7 +29,21 @@ def test_candidates_are_built_geometries(M, N, K, split):
         ksl = ops.tiled_slice_width(M, tiles)
         assert K % ksl == 0 and 1 <= groups <= min(K // ksl, 8)
         assert split or groups == 1
-        assert ops.tiles_per_workgroup(tiles) in (4, 8, 16)
+        assert ops.tiles_per_workgroup(tiles) in ((1, 2, 4) if tiles in KW else (4, 8, 16))
+
+
+def test_narrow_slices_get_the_k_split_across_waves():
+    """The qkv / o / gate_up slices of a Llama-3-70B rank on 8 GPUs at 16 rows: the forms with several
+    waves per tile are among the candidates; a SwiGLU matrix never gets 8 waves per tile (its gate and
+    up tiles must share a workgroup); wide matrices and more than 32 rows get none."""
+    assert {t for t, _ in ops.linear_tiled_candidates(1280, 8192, True, 16)} >= {304, 308}
+    assert (308, 1) in ops.linear_tiled_candidates(8192, 1024, False, 16)
+    gu = {t for t, _ in ops.linear_tiled_candidates(7168, 8192, False, 16, swiglu=True)}
+    assert gu & KW and 308 not in gu
+    assert not {t for t, _ in ops.linear_tiled_candidates(28672, 4096, False, 32, swiglu=True)} & KW
+    assert not {t for t, _ in ops.linear_tiled_candidates(1280, 8192, True, 64)} & KW
+    assert ops.tiled_slice_width(16, 308) == 1024 and ops.tiled_slice_width(32, 404) == 512
+    assert ops.tiles_per_workgroup(302) == 4 and ops.tiles_per_workgroup(308) == 1
 
 
 def test_rows_beyond_the_kernels_have_no_plan():

@@ -611,6 +611,209 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled2_kernel(
   }
 }
 
+// ---- K split across the WAVES of a workgroup (up to 32 rows): for matrices with few 16-row tiles
+// (the slices of a tensor-parallel rank: 80 tiles for the qkv projection of Llama-3-70B on 8 GPUs)
+// one wave per tile leaves most of the chip idle, and a K split across workgroups alone needs fp32
+// slabs and a consumer that adds them -- which a SwiGLU epilogue or a 16-bit output for an
+// all-reduce rules out.  Here a workgroup of 8 waves owns 8 / KW tiles; wave (tile, kq) streams
+// every KW-th register group of its tile's K range, the KW partial accumulators meet in LDS and
+// are added in wave order (a fixed order: the result does not depend on timing), and the tile's
+// lead wave runs the epilogue: store (+ bias), SwiGLU (the gate and up tiles of a column block sit
+// in one workgroup, KW <= 4) or fp32 slabs when K is ALSO split across workgroups (gridDim.y).
+// x staging, weight ring and MFMA mapping are those of linear_tiled_kernel.
+template <typename T, int MT, int KW, int KSL, int EPI>
+__global__ __launch_bounds__(512) void linear_tiled_kw_kernel(
+    uint16_t* __restrict__ y, float* __restrict__ partial, const uint16_t* __restrict__ x,
+    const uint16_t* __restrict__ wt, const uint16_t* __restrict__ bias, int M, int N, int K,
+    int64_t x_stride, int64_t y_stride, int tiles_total, int phases_total) {
+  constexpr int NW = 8, NT = NW * 64, ROWS = MT * 16, U = kTU;
+  constexpr int TPG = NW / KW;                 // tiles per workgroup
+  constexpr int ROWB = KSL * 2 + 32;           // padded LDS row (bytes)
+  constexpr int XBUF = ROWS * ROWB;
+  constexpr int G = KSL / 32 / U;              // register groups per phase
+  constexpr int GL = G / KW;                   // ... of which this wave takes GL
+  constexpr int D = 2;
+  constexpr int PU = GL >= D ? 1 : D / GL;     // phases per main-loop iteration: ring slots stay compile-time
+  static_assert(G % KW == 0 && GL >= 1 && (PU * GL) % D == 0, "ring slots must repeat every main-loop iteration");
+  static_assert(EPI != EPI_SILU_MUL || TPG % 2 == 0, "gate and up tiles of a column block share a workgroup");
+  static_assert(2 * XBUF >= NW * MT * 4 * 64 * 4, "the reduction reuses the x buffers");
+  static_assert(NT % (KSL / 8) == 0, "a thread must keep one column of the x slice");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * XBUF];
+
+  const int ubase = phases_total / static_cast<int>(gridDim.y), urem = phases_total % static_cast<int>(gridDim.y);
+  const int P = ubase + (static_cast<int>(blockIdx.y) < urem ? 1 : 0);
+  const int p0 = static_cast<int>(blockIdx.y) * ubase + min(static_cast<int>(blockIdx.y), urem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tl = wave / KW, kq = wave % KW;
+  const int c = lane & 15, h = lane >> 4;
+  const int tile_raw = blockIdx.x * TPG + tl;
+  const int tile = min(tile_raw, tiles_total - 1);
+  const int kgroup = blockIdx.y;
+
+  constexpr int NX = ROWS * (KSL / 8) / NT;
+  typedef unsigned int xvec __attribute__((ext_vector_type(4)));
+  auto x_issue = [&](xvec (&xs)[NX], int p) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int v = i * NT + tid;
+      const int row = v / (KSL / 8), col = v % (KSL / 8);
+      xs[i] = MI355_LD(xvec, x, x + static_cast<int64_t>(min(row, M - 1)) * x_stride +
+                                    static_cast<int64_t>(p) * KSL + col * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto x_commit = [&](xvec (&xs)[NX], int buf) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int v = i * NT + tid;
+      const int row = v / (KSL / 8), col = v % (KSL / 8);
+      *reinterpret_cast<xvec*>(&lds[buf * XBUF + row * ROWB + col * 16]) = xs[i];
+    }
+  };
+
+  // weight blocks are ordered [k group][tile][k-step in group]; this wave's ls-th group is group
+  // (ls / GL) * G + (ls % GL) * KW + kq of the workgroup's K range
+  const uint16_t* wbase = wt + (static_cast<int64_t>(p0) * G * tiles_total + tile) * (U * 512) + lane * 8;
+  const int64_t gstride = static_cast<int64_t>(tiles_total) * (U * 512);
+  const int groups_total = P * GL;
+  auto load_group = [&](uint4 (&wd)[U], int ls) {       // ls clamped: the tail re-loads the last group (never used)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int l = min(ls, groups_total - 1);
+    const uint16_t* p = wbase + ((l / GL) * G + (l % GL) * KW + kq) * gstride;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const u32x4 v = MI355_LDNT(u32x4, wt, p + u * 512);
+      wd[u] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](uint4 (&wd)[U], int buf, int g) {    // g = group index inside the phase
+    const unsigned char* xb = &lds[buf * XBUF + c * ROWB + g * (U * 64) + 16 * h];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        acc[m] = T::mfma(wd[u], *reinterpret_cast<const uint4*>(xb + u * 64 + m * 16 * ROWB), acc[m]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  uint4 ring[D][U];
+#pragma unroll
+  for (int j = 0; j < D - 1; ++j) load_group(ring[j], j);
+  {
+    xvec xs0[NX];
+    x_issue(xs0, p0);
+    x_commit(xs0, 0);
+  }
+  __syncthreads();
+  for (int p = 0; p < P; p += PU) {
+#pragma unroll
+    for (int pp = 0; pp < PU; ++pp) {
+      const int q = p + pp;
+      if (q >= P) break;
+      const bool more = q + 1 < P;
+      xvec xs[NX];
+      x_issue(xs, p0 + (more ? q + 1 : q));            // unconditional (the last phase re-loads its own slice, unused)
+#pragma unroll
+      for (int lg = 0; lg < GL; ++lg) {
+        load_group(ring[(pp * GL + lg + D - 1) % D], q * GL + lg + D - 1);
+        compute(ring[(pp * GL + lg) % D], q & 1, lg * KW + kq);
+      }
+      if (more) {
+        x_commit(xs, (q + 1) & 1);
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- the partial accumulators of a tile meet in LDS (the x buffers are dead): [wave][m-tile][r][lane]
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(lds);
+  const bool lead = kq == 0 && (EPI != EPI_SILU_MUL || (tl & 1) == 0);
+  if (!lead) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wave * MT + m) * 4 + r) * 64 + lane] = acc[m][r];
+  }
+  __syncthreads();
+  if (!lead || tile_raw >= tiles_total) return;
+#pragma unroll
+  for (int j = 1; j < KW; ++j)                           // wave order: a fixed order of additions
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[m][r] += red[(((wave + j) * MT + m) * 4 + r) * 64 + lane];
+
+  if (EPI == EPI_SILU_MUL) {                             // this wave: the gate tile; waves wave + KW ...: the up tile
+    if (tile_raw + 1 >= tiles_total) return;
+    const int F = N >> 1;
+    const int j0 = (tile_raw >> 1) * 16 + 4 * h;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int mm = 16 * m + c;
+      if (mm >= M) continue;
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float up = 0.f;
+#pragma unroll
+        for (int j = 0; j < KW; ++j) up += red[(((wave + KW + j) * MT + m) * 4 + r) * 64 + lane];
+        o[r] = silu_mul<T>(round_f<T>(acc[m][r]), round_f<T>(up));
+      }
+      uint16_t* yp = y + static_cast<int64_t>(mm) * y_stride + j0;
+      if (j0 + 3 < F) {
+        MI355_ST(uint2, y, yp, make_uint2(
+            static_cast<uint32_t>(T::from_f(o[0])) | (static_cast<uint32_t>(T::from_f(o[1])) << 16),
+            static_cast<uint32_t>(T::from_f(o[2])) | (static_cast<uint32_t>(T::from_f(o[3])) << 16)));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (j0 + r < F) MI355_ST(uint16_t, y, yp + r, T::from_f(o[r]));
+      }
+    }
+    return;
+  }
+  const int n0 = tile_raw * 16 + 4 * h;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (EPI == EPI_STORE && bias != nullptr) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n0 + r < N) bv[r] = T::to_f(MI355_LD(uint16_t, bias, bias + (n0 + r)));
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int mm = 16 * m + c;
+    if (mm >= M) continue;
+    if (EPI == EPI_PARTIAL) {
+      float* pp = partial + (static_cast<int64_t>(kgroup) * M + mm) * N + n0;
+      if (n0 + 3 < N && (N & 3) == 0) {
+        MI355_ST(float4, partial, pp, make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n0 + r < N) MI355_ST(float, partial, pp + r, acc[m][r]);
+      }
+    } else {
+      uint16_t* yp = y + static_cast<int64_t>(mm) * y_stride + n0;
+      if (n0 + 3 < N && (y_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0) {
+        MI355_ST(uint2, y, yp, make_uint2(
+            static_cast<uint32_t>(T::from_f(acc[m][0] + bv[0])) | (static_cast<uint32_t>(T::from_f(acc[m][1] + bv[1])) << 16),
+            static_cast<uint32_t>(T::from_f(acc[m][2] + bv[2])) | (static_cast<uint32_t>(T::from_f(acc[m][3] + bv[3])) << 16)));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n0 + r < N) MI355_ST(uint16_t, y, yp + r, T::from_f(acc[m][r] + bv[r]));
+      }
+    }
+  }
+}
+
 // Row-major [N, K] -> fragment-tiled (see the top of the file); rows beyond N are zero.
 // With `interleave_halves` the source rows are first reordered so that 16-row tiles
 // alternate between the first half (gate) and the second half (up) of the matrix.
@@ -800,6 +1003,32 @@ static bool launch_geometry2(int mt, int nw, int ksl, int epi, dim3 grid, hipStr
   return false;
 }
 
+// K split across waves (tiles_per_wg 302 / 304 / 308: 1024-wide x slices; 402 / 404: 512-wide): epilogues 0-2,
+// 16-bit weights, up to 32 rows.
+template <typename T, int MT, int KW, int KSL>
+static bool launch_cfg_kw(int epi, dim3 grid, hipStream_t s, MI355_LT_PARAMS) {
+#define MI355_LTKW(EPI_)                                                                                          \
+  hipLaunchKernelGGL((linear_tiled_kw_kernel<T, MT, KW, KSL, EPI_>), grid, dim3(512), 0, s, MI355_LT_ARGS)
+  if (epi == EPI_STORE) { MI355_LTKW(EPI_STORE); return true; }
+  if (epi == EPI_PARTIAL) { MI355_LTKW(EPI_PARTIAL); return true; }
+  if constexpr (KW <= 4) {
+    if (epi == EPI_SILU_MUL) { MI355_LTKW(EPI_SILU_MUL); return true; }
+  }
+#undef MI355_LTKW
+  return false;
+}
+
+template <typename T>
+static bool launch_geometry_kw(int mt, int kw, int ksl, int epi, dim3 grid, hipStream_t s, MI355_LT_PARAMS) {
+#define MI355_LTKW_GEOM(MT_, KW_, KSL_)             \
+  if (mt == MT_ && kw == KW_ && ksl == KSL_) return launch_cfg_kw<T, MT_, KW_, KSL_>(epi, grid, s, MI355_LT_ARGS);
+  MI355_LTKW_GEOM(1, 2, 1024) MI355_LTKW_GEOM(1, 4, 1024) MI355_LTKW_GEOM(1, 8, 1024)
+  MI355_LTKW_GEOM(2, 2, 1024) MI355_LTKW_GEOM(2, 4, 1024) MI355_LTKW_GEOM(2, 8, 1024)
+  MI355_LTKW_GEOM(1, 2, 512) MI355_LTKW_GEOM(1, 4, 512) MI355_LTKW_GEOM(2, 2, 512) MI355_LTKW_GEOM(2, 4, 512)
+#undef MI355_LTKW_GEOM
+  return false;
+}
+
 // Shared argument checks + launch of both entry points.
 static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, float* partial, const void* x,
                                    int64_t x_stride, const void* w_tiled, const void* bias, int32_t M, int32_t N,
@@ -816,11 +1045,20 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
   // double-buffered x image keeps its LDS footprint.
   // 208 / 216: two tiles per wave (4 waves with the narrow slice / 8 waves with the wide one), 33..128 rows
   const bool two = tiles_per_wg == 208 || tiles_per_wg == 216;
+  // 302 / 304 / 308, 402 / 404: K split across 2 / 4 / 8 waves of an 8-wave workgroup (1024- / 512-wide slices)
+  const bool kws = tiles_per_wg == 302 || tiles_per_wg == 304 || tiles_per_wg == 308 || tiles_per_wg == 402 ||
+                   tiles_per_wg == 404;
   const int nw = two ? (tiles_per_wg - 200) / 2 : tiles_per_wg % 100;
-  MI355_REQUIRE(two || ((nw == 4 || nw == 8) && (tiles_per_wg == nw || tiles_per_wg == nw + 100)), MI355_ERR_INVALID,
-                "%s: tiles_per_wg must be 4, 8, 104, 108, 208 or 216", name);
+  MI355_REQUIRE(two || kws || ((nw == 4 || nw == 8) && (tiles_per_wg == nw || tiles_per_wg == nw + 100)),
+                MI355_ERR_INVALID, "%s: tiles_per_wg must be 4, 8, 104, 108, 208, 216, 302, 304, 308, 402 or 404", name);
   const int mt = M <= 16 ? 1 : M <= 32 ? 2 : M <= 64 ? 4 : 8;
-  const int ksl = ((two ? tiles_per_wg == 208 : tiles_per_wg >= 100) ? 512 : 1024) / (mt <= 2 ? 1 : mt / 2);
+  const int ksl = kws ? (tiles_per_wg >= 400 ? 512 : 1024)
+                      : ((two ? tiles_per_wg == 208 : tiles_per_wg >= 100) ? 512 : 1024) / (mt <= 2 ? 1 : mt / 2);
+  MI355_REQUIRE(!kws || (M <= 32 && !norm && !reduce && fa.w_scale == nullptr), MI355_ERR_UNSUPPORTED,
+                "%s: the K split across waves (tiles_per_wg %d) is built for up to 32 rows, 16-bit weights and "
+                "epilogues 0-2", name, tiles_per_wg);
+  MI355_REQUIRE(!kws || epilogue != EPI_SILU_MUL || tiles_per_wg % 100 <= 4, MI355_ERR_UNSUPPORTED,
+                "%s: the SwiGLU epilogue needs the gate and up tiles in one workgroup: at most 4 waves per tile", name);
   MI355_REQUIRE(!two || (M > 32 && !norm && !reduce), MI355_ERR_UNSUPPORTED,
                 "%s: two tiles per wave (tiles_per_wg %d) is built for 33..128 rows and epilogues 0-2", name, tiles_per_wg);
   MI355_REQUIRE(N > 0 && K > 0 && K % ksl == 0, MI355_ERR_UNSUPPORTED,
@@ -862,7 +1100,7 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
                   "%s: SwiGLU epilogue needs N %% 32 == 0 and no bias", name);
   if (M == 0) return MI355_OK;
   const int tiles_total = (N + 15) / 16;
-  const int tiles_wg = two ? 2 * nw : nw;
+  const int tiles_wg = kws ? 8 / (tiles_per_wg % 100) : two ? 2 * nw : nw;
   dim3 grid((tiles_total + tiles_wg - 1) / tiles_wg, k_groups);
   hipStream_t s = static_cast<hipStream_t>(stream);
   auto* yp = static_cast<uint16_t*>(y);
@@ -870,7 +1108,12 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
   auto* wp = static_cast<const uint16_t*>(w_tiled);
   auto* bp = static_cast<const uint16_t*>(bias);
   bool ok;
-  if (two)
+  if (kws)
+    ok = dtype == MI355_BF16 ? launch_geometry_kw<BF16>(mt, tiles_per_wg % 100, ksl, epilogue, grid, s, yp, partial, xp, wp, bp,
+                                                        M, N, K, x_stride, y_stride, tiles_total, phases)
+                             : launch_geometry_kw<F16>(mt, tiles_per_wg % 100, ksl, epilogue, grid, s, yp, partial, xp, wp, bp,
+                                                       M, N, K, x_stride, y_stride, tiles_total, phases);
+  else if (two)
     ok = dtype == MI355_BF16 ? launch_geometry2<BF16>(mt, nw, ksl, epilogue, grid, s, yp, partial, xp, wp, bp, M, N, K,
                                                       x_stride, y_stride, tiles_total, phases, fa.w_scale)
                              : launch_geometry2<F16>(mt, nw, ksl, epilogue, grid, s, yp, partial, xp, wp, bp, M, N, K,
@@ -881,8 +1124,8 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
                              : launch_geometry<F16>(mt, nw, ksl, epilogue, norm, grid, s, yp, partial, xp, wp, bp, M, N, K,
                                                     x_stride, y_stride, tiles_total, phases, fa);
   MI355_REQUIRE(ok, MI355_ERR_UNSUPPORTED,
-                "%s: no kernel for M %d with tiles_per_wg %d, epilogue %d%s (M <= 32: 4/8/104/108, fused and fp8 "
-                "forms 8/104; M <= 64: 8/104/108/208/216; M <= 128: 8/216)", name, M, tiles_per_wg, epilogue,
+                "%s: no kernel for M %d with tiles_per_wg %d, epilogue %d%s (M <= 32: 4/8/104/108/302/304/308/402/404, "
+                "fused and fp8 forms 8/104; M <= 64: 8/104/108/208/216; M <= 128: 8/216)", name, M, tiles_per_wg, epilogue,
                 norm ? " + norm prologue" : "");
   return check_launch(name);
 }

@@ -107,15 +107,13 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
             log.warning("no *.safetensors under %r: using seeded synthetic weights (nothing is downloaded)",
                         args.model)
         weights = W.synthetic(cfg, dtype, device, seed=args.seed, **kw)
-    # the runner keeps a second, fragment-tiled copy of the decode-time matrices (the o
-    # projection only without tensor parallelism)
+    # the runner keeps a second, fragment-tiled copy of the decode-time matrices
     fp8 = (args.quantization or "").lower() == "fp8"
     if cfg.family == "opt":
         tiled_bytes = 0                               # its decode GEMMs stream the row-major weights
     else:
         tiled_bytes = sum(t.numel() * (1 if fp8 else t.element_size()) for lw in weights.layers
-                          for t in (lw.qkv_w, lw.gate_up_w) + ((lw.o_w,) if tp == 1 else ())
-                          + (() if shard_mlp else (lw.down_w,)))
+                          for t in (lw.qkv_w, lw.gate_up_w, lw.o_w, lw.down_w))
         tiled_bytes += weights.lm_head.numel() * weights.lm_head.element_size()
     num_blocks = plan_num_blocks(args, cfg, tp, len(weights.layers), max_model_len,
                                  torch.empty(0, dtype=dtype).element_size(), device, extra_reserve=tiled_bytes)

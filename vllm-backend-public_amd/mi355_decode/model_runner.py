@@ -177,9 +177,10 @@ class ModelRunner:
     def _init_tiled(self, want: Optional[bool]) -> None:
         """Fragment-tiled copies of the weights for decode batches of up to 128 rows.
         A projection whose output is all-reduced (o under tensor parallelism, down when the
-        MLP is sharded) stays a library GEMM: its output has to be a 16-bit tensor for the
-        collective, and the K-split kernel's strength is handing fp32 partial sums to the next
-        kernel.
+        MLP is sharded) has to hand the collective a 16-bit tensor: it cannot split K across
+        workgroups into fp32 slabs, and runs the tiled kernel with the store epilogue (for the
+        narrow slices of a rank: K split across the waves of a workgroup) or a library GEMM,
+        whichever the timing picks.
 
         `want` True: every projection that has a tiled kernel for the step's row count uses it;
         False: library GEMMs only; None (the serving default, MI355_TILED_LINEARS=1/0 forces
@@ -200,10 +201,9 @@ class ModelRunner:
             return
         self.tiled_shapes = {"qkv": (self.qw, self.H, True), "gu": (2 * self.F, self.H, False),
                              "lm_head": (self.Vl, self.H, False)}
-        if self.tp_size == 1:
-            self.tiled_shapes["o"] = (self.H, self.nh * self.d, True)
-        if not self.mlp_sharded:
-            self.tiled_shapes["down"] = (self.H, self.F, True)
+        # third field: the output may be fp32 slabs of a K split across workgroups (summed by the next kernel)
+        self.tiled_shapes["o"] = (self.H, self.nh * self.d, self.tp_size == 1)
+        self.tiled_shapes["down"] = (self.H, self.F, not self.mlp_sharded)
         ms = []                                       # the kernels' row-count classes a bucket can fall in
         for m in (16, 32, 64, 128):
             ms.append(m)
@@ -225,7 +225,7 @@ class ModelRunner:
         size = {k: 0 for k in ("qkv", "o", "down")}
         for m in ms:                                  # room for the deepest K split the tuner may pick (8 slabs)
             for k in size:
-                if k in self._tiled_plan(m):
+                if k in self._tiled_plan(m) and self.tiled_shapes[k][2]:
                     size[k] = max(size[k], 8 * min(m, max(self.max_num_seqs, 16)) * self.tiled_shapes[k][0])
         self.part_qkv = torch.empty(max(size["qkv"], 4), **f32)
         self.part_o = torch.empty(max(size["o"], 4), **f32)
@@ -340,19 +340,25 @@ class ModelRunner:
                                                      k_groups=g_, epilogue=P),
                                                   attend(i, partial=self.part_qkv, num_slabs=g_, bias=W[i].qkv_b)),
                         lambda i: (torch.mm(x, W[i].qkv_w.t(), out=qkv), attend(i, qkv=qkv))),
-                "o": (lambda t_, g_: lambda i: (lt(attn, T[i]["o"], self.H, partial=self.part_o, tiles_per_wg=t_,
-                                                   k_groups=g_, epilogue=P),
-                                                ops.fused_add_rms_norm_partial(self.part_o, g_, resid, W[i].post_norm,
-                                                                               eps, x)),
+                "o": ((lambda t_, g_: lambda i: (lt(attn, T[i]["o"], self.H, partial=self.part_o, tiles_per_wg=t_,
+                                                    k_groups=g_, epilogue=P),
+                                                 ops.fused_add_rms_norm_partial(self.part_o, g_, resid, W[i].post_norm,
+                                                                                eps, x)))
+                      if self.tp_size == 1 else
+                      (lambda t_, g_: lambda i: (lt(attn, T[i]["o"], self.H, out=o, tiles_per_wg=t_),
+                                                 ops.fused_add_rms_norm(o, resid, W[i].post_norm, eps, out=x))),
                       lambda i: (torch.mm(attn, W[i].o_w.t(), out=o),
                                  ops.fused_add_rms_norm(o, resid, W[i].post_norm, eps, out=x))),
                 "gu": (lambda t_, g_: lambda i: lt(x, T[i]["gu"], 2 * self.F, out=act, tiles_per_wg=t_,
                                                    epilogue=ops.EPI_SILU_MUL),
                        lambda i: (torch.mm(x, W[i].gate_up_w.t(), out=gu), ops.silu_and_mul(gu, out=act))),
-                "down": (lambda t_, g_: lambda i: (lt(act, T[i]["down"], self.H, partial=self.part_dn, tiles_per_wg=t_,
-                                                      k_groups=g_, epilogue=P),
-                                                   ops.fused_add_rms_norm_partial(self.part_dn, g_, resid,
-                                                                                  W[i].input_norm, eps, x)),
+                "down": ((lambda t_, g_: lambda i: (lt(act, T[i]["down"], self.H, partial=self.part_dn, tiles_per_wg=t_,
+                                                       k_groups=g_, epilogue=P),
+                                                    ops.fused_add_rms_norm_partial(self.part_dn, g_, resid,
+                                                                                   W[i].input_norm, eps, x)))
+                         if not self.mlp_sharded else
+                         (lambda t_, g_: lambda i: (lt(act, T[i]["down"], self.H, out=dn, tiles_per_wg=t_),
+                                                    ops.fused_add_rms_norm(dn, resid, W[i].input_norm, eps, out=x))),
                          lambda i: (torch.mm(act, W[i].down_w.t(), out=dn),
                                     ops.fused_add_rms_norm(dn, resid, W[i].input_norm, eps, out=x))),
                 "lm_head": (lambda t_, g_: lambda i: ops.linear_tiled(x, self.lm_head_tiled, self.Vl,
@@ -365,7 +371,7 @@ class ModelRunner:
                     tiled_form, lib_fn = forms[k]
                     n, kk, split = self.tiled_shapes[k]
                     best, best_us = avail[k], None
-                    for cand in ops.linear_tiled_candidates(n, kk, split, b):
+                    for cand in ops.linear_tiled_candidates(n, kk, split, b, swiglu=(k == "gu")):
                         if k == "qkv" and cand[1] > self.QKV_MAX_SLABS:
                             continue
                         try:
@@ -436,8 +442,10 @@ class ModelRunner:
         td, gd = plans.get("down", (0, 1))
         tiled = self.tiled if self.tiled is not None else [None] * self.L
 
+        slabs_o, slabs_dn = self.tp_size == 1, not self.mlp_sharded     # else: a 16-bit output for the all-reduce
+
         def add_mlp_and_norm(weight):
-            if mode["down"]:
+            if mode["down"] and slabs_dn:
                 ops.fused_add_rms_norm_partial(self.part_dn, gd, resid, weight, self.eps, x)
             else:
                 ops.fused_add_rms_norm(dn, resid, weight, self.eps, out=x)
@@ -460,11 +468,14 @@ class ModelRunner:
                 ops.paged_attn_decode_fused(qkv, self.cos_sin, slots, self.k_cache[i], self.v_cache[i], bt, ctx,
                                             self.nh, self.nkv, self.d, self.scale, num_splits=splits,
                                             workspace=self.attn_ws, out=attn)
-            if mode["o"]:
+            if mode["o"] and slabs_o:
                 self._linear_tiled(attn, tw["o"], self.H, partial=self.part_o, tiles_per_wg=to, k_groups=go, epilogue=P)
                 ops.fused_add_rms_norm_partial(self.part_o, go, resid, lw.post_norm, self.eps, x)
             else:
-                torch.mm(attn, lw.o_w.t(), out=o)
+                if mode["o"]:
+                    self._linear_tiled(attn, tw["o"], self.H, out=o, tiles_per_wg=to)
+                else:
+                    torch.mm(attn, lw.o_w.t(), out=o)
                 self._allreduce(o)
                 ops.fused_add_rms_norm(o, resid, lw.post_norm, self.eps, out=x)
             if mode["gu"]:
@@ -472,11 +483,14 @@ class ModelRunner:
             else:
                 torch.mm(x, lw.gate_up_w.t(), out=gu)
                 ops.silu_and_mul(gu, out=act)
-            if mode["down"]:
+            if mode["down"] and slabs_dn:
                 self._linear_tiled(act, tw["down"], self.H, partial=self.part_dn, tiles_per_wg=td, k_groups=gd,
                                    epilogue=P)
             else:
-                torch.mm(act, lw.down_w.t(), out=dn)
+                if mode["down"]:
+                    self._linear_tiled(act, tw["down"], self.H, out=dn, tiles_per_wg=td)
+                else:
+                    torch.mm(act, lw.down_w.t(), out=dn)
                 if self.mlp_sharded:
                     self._allreduce(dn)
         add_mlp_and_norm(self.w.final_norm)

@@ -510,15 +510,23 @@ SUMSQ_ROWS = 32                      # row pitch of the sum-of-squares tables
 LINEAR_TILED_MAX_M = 128
 
 
+KW_CODES = (302, 304, 308, 402, 404)   # K split across 2 / 4 / 8 waves of an 8-wave workgroup (4xx: 512-wide x slices)
+
+
 def tiled_slice_width(M: int, tiles_per_wg: int) -> int:
     """K slice of x a workgroup of linear_tiled stages at a time."""
+    if tiles_per_wg in KW_CODES:
+        return 512 if tiles_per_wg >= 400 else 1024
     mt = 1 if M <= 16 else 2 if M <= 32 else 4 if M <= 64 else 8
     narrow = tiles_per_wg in (104, 108, 208)      # 216 (two tiles per wave, 8 waves) stages the wide slice
     return (512 if narrow else 1024) // (1 if mt <= 2 else mt // 2)
 
 
 def tiles_per_workgroup(tiles_per_wg: int) -> int:
-    """Weight tiles one workgroup covers for a tiles_per_wg code (208 / 216: two tiles per wave)."""
+    """Weight tiles one workgroup covers for a tiles_per_wg code (208 / 216: two tiles per wave;
+    30x / 40x: 8 waves, x waves per tile)."""
+    if tiles_per_wg in KW_CODES:
+        return 8 // (tiles_per_wg % 100)
     return {208: 8, 216: 16}.get(tiles_per_wg, tiles_per_wg % 100)
 
 
@@ -557,11 +565,13 @@ def plan_linear_tiled(N: int, K: int, split_k: bool, M: int = 32):
     return None
 
 
-def linear_tiled_candidates(N: int, K: int, split_k: bool, M: int = 32):
+def linear_tiled_candidates(N: int, K: int, split_k: bool, M: int = 32, swiglu: bool = False):
     """Every (tiles_per_wg, k_groups) worth timing for linear_tiled on an [N, K] weight and M rows:
     both workgroup shapes that every kernel form (fp8, fused epilogues) is built for, K split into
     1, 2, 4 or 8 groups when the caller can take partial sums, beyond 32 rows also the forms with
-    two tiles per wave (208 / 216), kept if the launch has between 64 and 1024 workgroups.  Not
+    two tiles per wave (208 / 216), kept if the launch has between 64 and 1024 workgroups; up to 32
+    rows and few tiles also the forms that split K across the waves of a workgroup (`swiglu`: the
+    gate / up pair must share a workgroup, at most 4 waves per tile).  Not
     every form exists for every code (fp8 at up to 32 rows: 8 and 104 only): the caller skips a
     candidate the library refuses.  plan_linear_tiled's choice comes first."""
     first = plan_linear_tiled(N, K, split_k, M)
@@ -577,6 +587,17 @@ def linear_tiled_candidates(N: int, K: int, split_k: bool, M: int = 32):
         for g in ((1, 2, 4, 8) if split_k else (1,)):
             if g <= K // ksl and 64 <= wgs * g <= 1024 and (tiles, g) not in out:
                 out.append((tiles, g))
+    if M <= 32 and tiles_total < 8 * 160:
+        # few tiles (a tensor-parallel rank's slice): K split across the waves of a workgroup, the
+        # only way to more waves when the output must be 16-bit or gated (no slabs)
+        for tiles in KW_CODES:
+            ksl = tiled_slice_width(M, tiles)
+            if K % ksl or (swiglu and tiles % 100 > 4):
+                continue
+            wgs = -(-tiles_total // tiles_per_workgroup(tiles))
+            for g in ((1, 2, 4, 8) if split_k else (1,)):
+                if g <= K // ksl and 48 <= wgs * g <= 1024 and (tiles, g) not in out:
+                    out.append((tiles, g))
     return out
 
 
