@@ -112,7 +112,7 @@ def time_kernels(engine, batch, ctx_len):
             fn(i)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             for _ in range(reps):
                 for i in range(L):
                     fn(i)

@@ -284,7 +284,7 @@ class ModelRunner:
         fn(0)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local" if self.tp_size > 1 else "global"):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             for _ in range(reps):
                 for i in range(self.L):
                     fn(i)
@@ -652,10 +652,11 @@ class ModelRunner:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            # with a process group alive, its watchdog thread may touch the HIP runtime while this
-            # thread captures: only calls made by the capturing thread may end the capture
-            mode = "thread_local" if self.tp_size > 1 else "global"
-            with torch.cuda.graph(g, capture_error_mode=mode):
+            # Only calls made by the capturing thread may end the capture.  In the default ("global")
+            # mode a HIP call from ANY other thread of the process -- a process group's watchdog, a
+            # profiler's or a monitoring hook's sampler, another engine thread -- invalidates it, and
+            # the error then surfaces while the half-built graph is torn down.
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._decode_body(bucket)
         finally:                              # whatever happened, the caller's staged inputs come back
             self.in64.copy_(saved64)
