@@ -27,13 +27,14 @@
 // a few percent.
 //
 // Fused form (FUSE != 0): the rotary embedding and the KV store of the new token
-// happen here instead of in a kernel of their own.  Every wave forms the rotated
-// query fragments directly in the registers of the B operand (a lane's elements
-// [32ks + 8h, +8) and their rotation partners [.. + head_dim/2] are both its own,
-// so the rotation is lane-local); the workgroup whose token range holds the new
-// token rotates k, stores k and v to their pages, and the whole workgroup then
-// reads the pages as usual (release fence at workgroup scope + barrier between the
-// store and the loads; no other workgroup reads that slot in this launch).  The
+// happen here instead of in a kernel of their own.  The projection row of the
+// (sequence, kv head) -- the group's q heads, the k head, the v head -- is formed
+// once per workgroup: one thread per 8-element chunk (pair of chunks for the
+// rotating rows) loads it with coalesced loads, rotates q and k, and hands the
+// 16-bit row to the four waves through LDS, which read their MFMA operands
+// from there.  The workgroup whose token range holds the new token stores k and
+// v to their pages; the step that covers the new token takes its k row / v column
+// from registers, whatever the pages held, so nothing waits for that store.  The
 // projection comes either as packed 16-bit rows (FUSE == 1) or as the fp32
 // partial-sum slabs of a K-split GEMM (FUSE == 2: slab sum + bias, rounded, first).
 #include "common.h"
@@ -41,6 +42,25 @@
 #include <math.h>
 
 namespace mi355 {
+
+#ifdef MI355_ATTN_TRACE
+// experiment build: per-workgroup time stamps (100 MHz wall clock and shader clock) of the phases
+__device__ unsigned long long g_attn_trace[4096 * 16];
+#define MI355_STAMP(slot)                                                                                  \
+  do {                                                                                                     \
+    if (threadIdx.x == 0) {                                                                                \
+      const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                      \
+      if (wg_ < 4096) {                                                                                    \
+        g_attn_trace[wg_ * 16 + 2 * (slot)] = wall_clock64();                                              \
+        g_attn_trace[wg_ * 16 + 2 * (slot) + 1] = clock64();                                               \
+      }                                                                                                    \
+    }                                                                                                      \
+  } while (0)
+#define MI355_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define MI355_STAMP(slot)
+#define MI355_WAIT_ALL()
+#endif
 
 constexpr int kDecodeThreads = 256;
 constexpr int kDecodeWaves = kDecodeThreads / 64;
@@ -117,35 +137,12 @@ struct Proj8 {
       float bb[8];
       unpack8<T>(raw, bb);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = round_f<T>(f[j] + has * bb[j]);
+      for (int j = 0; j < 8; ++j) f[j] = round_f<T>(pin_f32(f[j] + has * bb[j]));   // fp32 sum first, then one rounding
     } else {
       unpack8<T>(raw, f);
     }
   }
 };
-
-// one element of the projection row, as a 16-bit word
-template <typename T, int FUSE, int SLABS>
-__device__ __forceinline__ uint16_t load_proj1(const uint16_t* q, int64_t q_stride, const RopeArgs& ra, int seq,
-                                               int width, int col) {
-  if (FUSE == 2) {
-    const float* pr = ra.partial + static_cast<int64_t>(seq) * width + col;
-    float f = 0.f;
-    if (SLABS > 0) {
-      float v[SLABS > 0 ? SLABS : 1];
-#pragma unroll
-      for (int s = 0; s < SLABS; ++s) v[s] = MI355_LD(float, ra.partial, pr + s * ra.slab_stride);
-#pragma unroll
-      for (int s = 0; s < SLABS; ++s) f += v[s];
-    } else {
-      for (int s = 0; s < ra.num_slabs; ++s) f += MI355_LD(float, ra.partial, pr + s * ra.slab_stride);
-    }
-    f += (ra.bias != nullptr ? 1.f : 0.f) *
-         T::to_f(MI355_LD(uint16_t, ra.bias != nullptr ? ra.bias : ra.cos_sin, ra.bias != nullptr ? ra.bias + col : ra.cos_sin));
-    return T::from_f(f);
-  }
-  return MI355_LD(uint16_t, q, q + static_cast<int64_t>(seq) * q_stride + col);
-}
 
 // rotate-half rotation of 8 pairs; every product and the sum rounded to the 16-bit type
 template <typename T>
@@ -171,6 +168,7 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
   constexpr int NT = D / 16;  // 16-row tiles of head_dim for PV
   constexpr int BS = MI355_BLOCK_SIZE;
 
+  MI355_STAMP(0);
   const int seq = blockIdx.x, kvh = blockIdx.y, split = blockIdx.z;
   const int group = num_heads / num_kv_heads;
   const int lane = threadIdx.x & 63;
@@ -178,6 +176,28 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
   // scalar unit (a vector lookup would have to wait for vmcnt(0), i.e. for every K/V load in flight)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, h = lane >> 4;
+
+  // Fused forms: the projection row of this (sequence, kv head) -- the group's q heads, the k head, the
+  // v head -- is formed ONCE per workgroup, by as many threads as it has 8-element chunks, with
+  // coalesced loads, and handed to the waves through LDS.  (Every wave loading and rotating its own
+  // copy straight into the MFMA operand layout cost ~70 load instructions per wave, most lanes
+  // fetching duplicates: 6 us of a 13 us kernel.)
+  //   rotating rows (q heads, then k): thread (row, j) holds the pair chunks [8j, +8) and
+  //   [D/2 + 8j, +8) of its row and rotates them; the v row: 8 elements per thread, no rotation.
+  // The row's loads go out before the K/V page loads of the wave's first stages, so that the wait
+  // for the row leaves those in flight (loads return in order).  Once the page loads of 256
+  // workgroups are queued the row still takes ~4 us to arrive; measured alternatives: the row's
+  // loads at the kernel's first instruction (no sooner, and the context length later), page loads
+  // only after the row is in LDS (+0.8 us), only the first stage before it (+0.1 us).
+  constexpr int CH = D / 16;                         // chunks of 8 rotation pairs per row
+  const int width = (num_heads + 2 * num_kv_heads) * D;
+  const int kcol = (num_heads + kvh) * D, vcol = (num_heads + num_kv_heads + kvh) * D;
+  const int rot_items = (group + 1) * CH;            // <= 17 * 8
+  const bool rot = FUSE != 0 && static_cast<int>(threadIdx.x) < rot_items;
+  const bool isv = FUSE != 0 && !rot && static_cast<int>(threadIdx.x) < rot_items + D / 8;
+  const int row = rot ? static_cast<int>(threadIdx.x) / CH : group + 1;
+  const int j8 = 8 * (rot ? static_cast<int>(threadIdx.x) % CH : static_cast<int>(threadIdx.x) - rot_items);
+  Proj8<T, FUSE, SLABS> p1, p2;
 
   // Without splits the block-table entries of a wave's first step do not depend on the context
   // length: their (vector) loads go out before the (scalar) context-length load, so the two
@@ -193,6 +213,9 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
   int ctx = MI355_LD(int32_t, context_lens, context_lens + seq);
   const int ctx_cap = max_blocks * BS;
   ctx = ctx < 0 ? 0 : (ctx > ctx_cap ? ctx_cap : ctx);
+#ifdef MI355_ATTN_TRACE
+  if (ctx >= 0) MI355_STAMP(1);
+#endif
   // token range of this split: multiples of one workgroup pass (4 waves x 32)
   int per_split = (ctx + num_splits - 1) / num_splits;
   per_split = (per_split + kStep * kDecodeWaves - 1) / (kStep * kDecodeWaves) * (kStep * kDecodeWaves);
@@ -231,11 +254,17 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
                      MI355_LD(int32_t, block_tables, bt + min(bi + 1, last_blk_idx)));
   };
   int tb = t_begin + kStep * wave;
-  if (!SPLIT) {
-    issue_page_loads(kv[0], e0, e1);
-  } else {
-    issue_loads(kv[0], tb);
-  }
+  // the K/V loads of the wave's first kStages steps; in the fused forms they go out AFTER the loads of
+  // the prologue, so that the wait for the prologue's values leaves them in flight (loads return in order)
+  auto issue_first_stages = [&]() {
+    if (!SPLIT) {
+      issue_page_loads(kv[0], e0, e1);
+    } else {
+      issue_loads(kv[0], tb);
+    }
+#pragma unroll
+    for (int j = 1; j < kStages; ++j) issue_loads(kv[j], tb + j * kStep * kDecodeWaves);
+  };
 
   // Q fragments (B operand): column c = head within the group
   uint4 qf[KS];
@@ -251,52 +280,55 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) qf[ks] = MI355_LD(uint4, q, qp + 32 * ks);
     }
+    issue_first_stages();
   } else {
-    const int width = (num_heads + 2 * num_kv_heads) * D;
+    __shared__ __attribute__((aligned(16))) uint16_t lds_new[(16 + 2) * D];   // rows: q heads (<= 16) | k | v
     // the new token sits at position ctx - 1: no separate position array, no extra dependent load
     int64_t pos = ctx - 1;
     pos = pos < 0 ? 0 : (pos >= ra.max_position ? ra.max_position - 1 : pos);
     const uint16_t* cs = ra.cos_sin + pos * D;
     const bool owner = ctx > 0 && t_new >= t_begin && t_new < t_begin + per_split;
-    const int kcol = (num_heads + kvh) * D, vcol = (num_heads + num_kv_heads + kvh) * D;
-    // Every load of the prologue goes out before the first value is used, in straight-line code
-    // (lanes beyond the group and workgroups that do not own the new token compute values they
-    // drop): the rotation then waits once, not once per branch or per chunk.
-    const int hq = c < group ? c : 0;
     const int64_t slot = MI355_LD(int64_t, ra.slots, ra.slots + seq);
-    Proj8<T, FUSE, SLABS> pq1[KS / 2], pq2[KS / 2], pk1[KS / 2], pk2[KS / 2];
-    uint4 cosr[KS / 2], sinr[KS / 2];
-#pragma unroll
-    for (int ks = 0; ks < KS / 2; ++ks) {
-      cosr[ks] = MI355_LD(uint4, ra.cos_sin, cs + 32 * ks + 8 * h);
-      sinr[ks] = MI355_LD(uint4, ra.cos_sin, cs + D / 2 + 32 * ks + 8 * h);
-      const int col = (kvh * group + hq) * D + 8 * h + 32 * ks;
-      pq1[ks].issue(q, q_stride, ra, seq, width, col);
-      pq2[ks].issue(q, q_stride, ra, seq, width, col + D / 2);
-      pk1[ks].issue(q, q_stride, ra, seq, width, kcol + 8 * h + 32 * ks);   // the k row: one more "head"
-      pk2[ks].issue(q, q_stride, ra, seq, width, kcol + 8 * h + 32 * ks + D / 2);
+    uint4 cosv = make_uint4(0, 0, 0, 0), sinv = make_uint4(0, 0, 0, 0);
+    if (rot) {
+      const int base = row < group ? (kvh * group + row) * D : kcol;
+      p1.issue(q, q_stride, ra, seq, width, base + j8);
+      p2.issue(q, q_stride, ra, seq, width, base + D / 2 + j8);
+      cosv = MI355_LD(uint4, ra.cos_sin, cs + j8);            // the same rows for every layer of a step: L2 hits
+      sinv = MI355_LD(uint4, ra.cos_sin, cs + D / 2 + j8);
+    } else if (isv) {
+      p1.issue(q, q_stride, ra, seq, width, vcol + j8);
     }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) vnew[n] = load_proj1<T, FUSE, SLABS>(q, q_stride, ra, seq, width, vcol + 16 * n + c);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < KS / 2; ++ks) {
+    issue_first_stages();
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef MI355_ATTN_TRACE
+    if (rot && p1.a[0].x == 12345.678f) MI355_STAMP(7);
+    if (rot) MI355_STAMP(7);                       // after the first slab vector of thread 0 has arrived
+#endif
+    if (rot) {
       float co[8], si[8], x1[8], x2[8], o1[8], o2[8];
-      unpack8<T>(cosr[ks], co);
-      unpack8<T>(sinr[ks], si);
-      pq1[ks].finish(x1, ra);
-      pq2[ks].finish(x2, ra);
+      unpack8<T>(cosv, co);
+      unpack8<T>(sinv, si);
+      p1.finish(x1, ra);
+      p2.finish(x2, ra);
       rotate8<T>(x1, x2, co, si, o1, o2);
-      if (c < group) {
-        qf[ks] = pack8<T>(o1);
-        qf[ks + KS / 2] = pack8<T>(o2);
-      }
-      pk1[ks].finish(x1, ra);
-      pk2[ks].finish(x2, ra);
-      rotate8<T>(x1, x2, co, si, o1, o2);
-      knew[ks] = pack8<T>(o1);
-      knew[ks + KS / 2] = pack8<T>(o2);
+      *reinterpret_cast<uint4*>(&lds_new[row * D + j8]) = pack8<T>(o1);
+      *reinterpret_cast<uint4*>(&lds_new[row * D + D / 2 + j8]) = pack8<T>(o2);
+    } else if (isv) {
+      float f[8];
+      p1.finish(f, ra);
+      *reinterpret_cast<uint4*>(&lds_new[(group + 1) * D + j8]) = pack8<T>(f);
     }
+    __syncthreads();
+    if (c < group) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(&lds_new[c * D + 32 * ks + 8 * h]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) knew[ks] = *reinterpret_cast<const uint4*>(&lds_new[group * D + 32 * ks + 8 * h]);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) vnew[n] = lds_new[(group + 1) * D + 16 * n + c];
     if (owner) {
       // the pages get the new token too (for the steps to come); nobody in this launch waits for it
       if (slot >= 0 && slot < static_cast<int64_t>(num_blocks) * BS && wave == 0) {
@@ -316,6 +348,9 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
     }
   }
 
+#ifdef MI355_ATTN_TRACE
+  if (qf[0].x != 0x12345678u) MI355_STAMP(2);        // depends on the rotated query: after the prologue's loads
+#endif
   float m = -INFINITY, l = 0.f;
   f32x4 o[NT];
 #pragma unroll
@@ -404,9 +439,11 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
     for (int n = 0; n < NT; ++n) o[n] = T::mfma(kvr.vf[n], pf, o[n]);
 
   };
-#pragma unroll
-  for (int j = 1; j < kStages; ++j) issue_loads(kv[j], tb + j * kStep * kDecodeWaves);
   __builtin_amdgcn_sched_barrier(0);
+#ifdef MI355_ATTN_TRACE
+  MI355_WAIT_ALL();
+  MI355_STAMP(3);                                     // every K/V load issued so far has arrived
+#endif
   while (tb < t_end) {
 #pragma unroll
     for (int j = 0; j < kStages; ++j) {
@@ -418,6 +455,9 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
     }
   }
 
+#ifdef MI355_ATTN_TRACE
+  if (l >= 0.f) MI355_STAMP(4);
+#endif
   // column sums live on the 4 lanes (c, h = 0..3)
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
@@ -435,35 +475,40 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
     lds_l[wave][c] = l;
   }
   __syncthreads();
+  MI355_STAMP(5);
 
-  for (int idx = threadIdx.x; idx < group * D; idx += kDecodeThreads) {
-    const int hh = idx / D, d = idx % D;
+  // two adjacent head_dim elements per thread: one pass for a group of 4 heads of 128
+  for (int idx = threadIdx.x; idx < group * (D / 2); idx += kDecodeThreads) {
+    const int hh = idx / (D / 2), d = 2 * (idx % (D / 2));
     float mg = lds_m[0][hh];
 #pragma unroll
     for (int w = 1; w < kDecodeWaves; ++w) mg = fmaxf(mg, lds_m[w][hh]);
-    float acc = 0.f, lsum = 0.f;
+    float acc0 = 0.f, acc1 = 0.f, lsum = 0.f;
     if (mg != -INFINITY) {
 #pragma unroll
       for (int w = 0; w < kDecodeWaves; ++w) {
         const float f = exp2f(lds_m[w][hh] - mg);
-        acc += f * lds_o[w][d * 16 + hh];
+        acc0 += f * lds_o[w][d * 16 + hh];
+        acc1 += f * lds_o[w][(d + 1) * 16 + hh];
         lsum += f * lds_l[w][hh];
       }
     }
     const int head = kvh * group + hh;
     if (num_splits == 1) {
-      const float val = lsum > 0.f ? acc / lsum : 0.f;
-      MI355_ST(uint16_t, out, out + (static_cast<int64_t>(seq) * num_heads + head) * D + d, T::from_f(val));
+      const float v0 = lsum > 0.f ? acc0 / lsum : 0.f, v1 = lsum > 0.f ? acc1 / lsum : 0.f;
+      MI355_ST(uint32_t, out, out + (static_cast<int64_t>(seq) * num_heads + head) * D + d,
+               static_cast<uint32_t>(T::from_f(v0)) | (static_cast<uint32_t>(T::from_f(v1)) << 16));
     } else {
       // the partials are one buffer: [rows][splits][D] accumulators, then [rows][splits][2] statistics
       const int64_t pi = (static_cast<int64_t>(seq) * num_heads + head) * num_splits + split;
-      MI355_ST(float, part_o, part_o + pi * D + d, acc);
+      MI355_ST(float2, part_o, part_o + pi * D + d, make_float2(acc0, acc1));
       if (d == 0) {
         MI355_ST(float, part_o, part_ml + pi * 2, mg);
         MI355_ST(float, part_o, part_ml + pi * 2 + 1, lsum);
       }
     }
   }
+  MI355_STAMP(6);
 }
 
 // Combine the per-split partials: one workgroup per (sequence, head), D threads.
@@ -519,6 +564,12 @@ static int32_t launch_decode(void* out, const void* q, int64_t q_stride, void* k
 }
 
 }  // namespace mi355
+
+#ifdef MI355_ATTN_TRACE
+extern "C" int32_t mi355_attn_trace_read(unsigned long long* host, int32_t words) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(mi355::g_attn_trace), sizeof(unsigned long long) * words) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int64_t mi355_paged_attn_decode_workspace(int32_t num_seqs, int32_t num_heads,
                                                      int32_t head_dim, int32_t num_splits) {
