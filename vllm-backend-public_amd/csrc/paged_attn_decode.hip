@@ -228,12 +228,17 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
   // ---- loads of one 32-token step: K tiles a/b, then the V tiles.  kStages register sets: a wave
   // keeps the loads of its next kStages - 1 steps in flight while it computes one.
   KVRegs<KS, NT> kv[kStages];
-  auto issue_page_loads = [&](KVRegs<KS, NT>& r, int blk0, int blk1) {
+  // `live` (wave-uniform, 0 / 1): whether the step holds tokens of this wave's range.  The loads of a
+  // step beyond it are still issued (see issue_loads) but with the lane-dependent part of the address
+  // zeroed: all lanes then ask for the same 16 bytes and the instruction is ONE request to the cache
+  // instead of 16 -- at contexts around 160, two thirds of a launch's load instructions are such
+  // steps, and they queue in front of the loads that matter.
+  auto issue_page_loads = [&](KVRegs<KS, NT>& r, int blk0, int blk1, int live) {
     blk0 = min(max(blk0, 0), num_blocks - 1);
     blk1 = min(max(blk1, 0), num_blocks - 1);
     const int kblk = (c & 8) ? blk1 : blk0;
     const uint16_t* kp =
-        k_cache + ((static_cast<int64_t>(kblk) * num_kv_heads + kvh) * BS + koff) * D + 8 * h;
+        k_cache + (static_cast<int64_t>(kblk) * num_kv_heads + kvh) * (BS * D) + live * (koff * D + 8 * h);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       r.ka[ks] = MI355_LD(uint4, k_cache, kp + 32 * ks);
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
     }
     const int vblk = (h & 2) ? blk1 : blk0;
     const uint16_t* vp =
-        v_cache + ((static_cast<int64_t>(vblk) * num_kv_heads + kvh) * D + c) * BS + 8 * (h & 1);
+        v_cache + (static_cast<int64_t>(vblk) * num_kv_heads + kvh) * (D * BS) + live * (c * BS + 8 * (h & 1));
 #pragma unroll
     for (int n = 0; n < NT; ++n) r.vf[n] = MI355_LD(uint4, v_cache, vp + n * 16 * BS);
   };
@@ -251,14 +256,14 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
   auto issue_loads = [&](KVRegs<KS, NT>& r, int tb) {
     const int bi = min(tb / BS, last_blk_idx);
     issue_page_loads(r, MI355_LD(int32_t, block_tables, bt + bi),
-                     MI355_LD(int32_t, block_tables, bt + min(bi + 1, last_blk_idx)));
+                     MI355_LD(int32_t, block_tables, bt + min(bi + 1, last_blk_idx)), tb < t_end ? 1 : 0);
   };
   int tb = t_begin + kStep * wave;
   // the K/V loads of the wave's first kStages steps; in the fused forms they go out AFTER the loads of
   // the prologue, so that the wait for the prologue's values leaves them in flight (loads return in order)
   auto issue_first_stages = [&]() {
     if (!SPLIT) {
-      issue_page_loads(kv[0], e0, e1);
+      issue_page_loads(kv[0], e0, e1, tb < t_end ? 1 : 0);
     } else {
       issue_loads(kv[0], tb);
     }
