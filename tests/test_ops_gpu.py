@@ -675,6 +675,32 @@ def test_linear_tiled_k_split_across_waves(ops, dtype, M, N, K, bias, tiles):
             np.testing.assert_allclose(part[g], ref, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("M,tiles", [(33, 302), (64, 304), (50, 402), (65, 302), (128, 302)])
+@pytest.mark.parametrize("N,K,bias", [(4096, 7168, True), (1000, 1024, False)])
+def test_linear_tiled_k_split_across_waves_up_to_128_rows(ops, M, tiles, N, K, bias):
+    """The same geometries at 33..128 rows (the rank shapes of wide tensor-parallel batches): store,
+    slabs and the SwiGLU epilogue."""
+    dtype = "bfloat16"
+    rng = rng_for("tiled-kw-rows", M, tiles, N, K)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (N, K), dtype, 0.05)
+    b = grid(rng, (N,), dtype) if bias else None
+    xd, wt = dev(x, dtype), ops.tile_weights(dev(w, dtype))
+    y = host(ops.linear_tiled(xd, wt, N, dev(b, dtype) if bias else None, tiles_per_wg=tiles))
+    ref64 = x.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
+    err = np.abs(y - ref64)
+    assert (err <= _linear_tol(ref64, x, w, K, dtype)).all(), f"max err {err.max()}"
+    assert (y != R.linear(x, w, b, dtype)).mean() <= 0.02
+    part = ops.linear_tiled(xd, wt, N, k_groups=2, epilogue=ops.EPI_PARTIAL, tiles_per_wg=tiles).cpu().numpy()
+    np.testing.assert_allclose(part[0] + part[1], x.astype(np.float64) @ w.astype(np.float64).T, rtol=1e-4, atol=2e-3)
+    if N % 32 == 0:
+        wi = ops.tile_weights(dev(w, dtype), interleave_halves=True)
+        g = host(ops.linear_tiled(xd, wi, N, epilogue=ops.EPI_SILU_MUL, tiles_per_wg=tiles))
+        np.testing.assert_array_equal(g, host(ops.silu_and_mul(ops.linear_tiled(xd, wt, N, tiles_per_wg=tiles))))
+    from mi355_decode._lib import Mi355Error
+    with pytest.raises(Mi355Error, match="waves per tile need an x slice"):
+        ops.linear_tiled(xd, wt, N, tiles_per_wg=308)
+
+
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 @pytest.mark.parametrize("M,F,K", [(16, 3584, 8192), (7, 512, 1024), (32, 1536, 1024), (1, 64, 2048)])
 @pytest.mark.parametrize("tiles", [302, 304, 402, 404])

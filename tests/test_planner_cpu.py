@@ -11,7 +11,8 @@ SHAPES = [  # N, K, split_k: the projections of the benchmark models and of thei
     (1280, 8192, True), (8192, 1024, True), (7168, 8192, False), (16032, 4096, False), (1536, 4096, True),
 ]
 KW = {302, 304, 308, 402, 404}        # K split across the waves of a workgroup: up to 32 rows
-BUILT = {16: {4, 8, 104, 108} | KW, 32: {4, 8, 104, 108} | KW, 64: {8, 104, 108, 208, 216}, 128: {8, 216}}
+BUILT = {16: {4, 8, 104, 108} | KW, 32: {4, 8, 104, 108} | KW, 64: {8, 104, 108, 208, 216, 302, 304, 402},
+         128: {8, 216, 302}}
 
 
 @pytest.mark.parametrize("M", [1, 16, 17, 32, 33, 64, 65, 128])
@@ -41,8 +42,10 @@ def test_narrow_slices_get_the_k_split_across_waves():
     gu = {t for t, _ in ops.linear_tiled_candidates(7168, 8192, False, 16, swiglu=True)}
     assert gu & KW and 308 not in gu
     assert not {t for t, _ in ops.linear_tiled_candidates(28672, 4096, False, 32, swiglu=True)} & KW
-    assert not {t for t, _ in ops.linear_tiled_candidates(1280, 8192, True, 64)} & KW
+    assert {t for t, _ in ops.linear_tiled_candidates(4096, 7168, False, 64)} & KW == {302, 304, 402}
+    assert {t for t, _ in ops.linear_tiled_candidates(7168, 4096, False, 128, swiglu=True)} & KW == {302}
     assert ops.tiled_slice_width(16, 308) == 1024 and ops.tiled_slice_width(32, 404) == 512
+    assert ops.tiled_slice_width(64, 304) == 512 and ops.tiled_slice_width(128, 302) == 256
     assert ops.tiles_per_workgroup(302) == 4 and ops.tiles_per_workgroup(308) == 1
 
 

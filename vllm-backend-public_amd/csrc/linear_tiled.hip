@@ -611,7 +611,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled2_kernel(
   }
 }
 
-// ---- K split across the WAVES of a workgroup (up to 32 rows): for matrices with few 16-row tiles
+// ---- K split across the WAVES of a workgroup: for matrices with few 16-row tiles
 // (the slices of a tensor-parallel rank: 80 tiles for the qkv projection of Llama-3-70B on 8 GPUs)
 // one wave per tile leaves most of the chip idle, and a K split across workgroups alone needs fp32
 // slabs and a consumer that adds them -- which a SwiGLU epilogue or a 16-bit output for an
@@ -1003,8 +1003,8 @@ static bool launch_geometry2(int mt, int nw, int ksl, int epi, dim3 grid, hipStr
   return false;
 }
 
-// K split across waves (tiles_per_wg 302 / 304 / 308: 1024-wide x slices; 402 / 404: 512-wide): epilogues 0-2,
-// 16-bit weights, up to 32 rows.
+// K split across waves (tiles_per_wg 302 / 304 / 308: wide x slices; 402 / 404: narrow ones): epilogues 0-2,
+// 16-bit weights.
 template <typename T, int MT, int KW, int KSL>
 static bool launch_cfg_kw(int epi, dim3 grid, hipStream_t s, MI355_LT_PARAMS) {
 #define MI355_LTKW(EPI_)                                                                                          \
@@ -1025,6 +1025,9 @@ static bool launch_geometry_kw(int mt, int kw, int ksl, int epi, dim3 grid, hipS
   MI355_LTKW_GEOM(1, 2, 1024) MI355_LTKW_GEOM(1, 4, 1024) MI355_LTKW_GEOM(1, 8, 1024)
   MI355_LTKW_GEOM(2, 2, 1024) MI355_LTKW_GEOM(2, 4, 1024) MI355_LTKW_GEOM(2, 8, 1024)
   MI355_LTKW_GEOM(1, 2, 512) MI355_LTKW_GEOM(1, 4, 512) MI355_LTKW_GEOM(2, 2, 512) MI355_LTKW_GEOM(2, 4, 512)
+  // 33..128 rows: the x slice halves with every doubling of the rows (its double-buffered LDS image keeps
+  // its size), and a wave needs at least one register group of it: 2 or 4 waves per tile at up to 64 rows, 2 beyond
+  MI355_LTKW_GEOM(4, 2, 512) MI355_LTKW_GEOM(4, 4, 512) MI355_LTKW_GEOM(4, 2, 256) MI355_LTKW_GEOM(8, 2, 256)
 #undef MI355_LTKW_GEOM
   return false;
 }
@@ -1052,11 +1055,14 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
   MI355_REQUIRE(two || kws || ((nw == 4 || nw == 8) && (tiles_per_wg == nw || tiles_per_wg == nw + 100)),
                 MI355_ERR_INVALID, "%s: tiles_per_wg must be 4, 8, 104, 108, 208, 216, 302, 304, 308, 402 or 404", name);
   const int mt = M <= 16 ? 1 : M <= 32 ? 2 : M <= 64 ? 4 : 8;
-  const int ksl = kws ? (tiles_per_wg >= 400 ? 512 : 1024)
-                      : ((two ? tiles_per_wg == 208 : tiles_per_wg >= 100) ? 512 : 1024) / (mt <= 2 ? 1 : mt / 2);
-  MI355_REQUIRE(!kws || (M <= 32 && !norm && !reduce && fa.w_scale == nullptr), MI355_ERR_UNSUPPORTED,
-                "%s: the K split across waves (tiles_per_wg %d) is built for up to 32 rows, 16-bit weights and "
-                "epilogues 0-2", name, tiles_per_wg);
+  const int ksl = ((kws ? tiles_per_wg >= 400 : two ? tiles_per_wg == 208 : tiles_per_wg >= 100) ? 512 : 1024) /
+                  (mt <= 2 ? 1 : mt / 2);
+  MI355_REQUIRE(!kws || (!norm && !reduce && fa.w_scale == nullptr), MI355_ERR_UNSUPPORTED,
+                "%s: the K split across waves (tiles_per_wg %d) is built for 16-bit weights and epilogues 0-2", name,
+                tiles_per_wg);
+  MI355_REQUIRE(!kws || (tiles_per_wg % 100) * 128 <= ksl, MI355_ERR_UNSUPPORTED,
+                "%s: %d waves per tile need an x slice of at least %d columns, M %d stages %d (up to 64 rows: 302, 304, "
+                "402; up to 128 rows: 302)", name, tiles_per_wg % 100, (tiles_per_wg % 100) * 128, M, ksl);
   MI355_REQUIRE(!kws || epilogue != EPI_SILU_MUL || tiles_per_wg % 100 <= 4, MI355_ERR_UNSUPPORTED,
                 "%s: the SwiGLU epilogue needs the gate and up tiles in one workgroup: at most 4 waves per tile", name);
   MI355_REQUIRE(!two || (M > 32 && !norm && !reduce), MI355_ERR_UNSUPPORTED,
@@ -1125,7 +1131,8 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
                                                     x_stride, y_stride, tiles_total, phases, fa);
   MI355_REQUIRE(ok, MI355_ERR_UNSUPPORTED,
                 "%s: no kernel for M %d with tiles_per_wg %d, epilogue %d%s (M <= 32: 4/8/104/108/302/304/308/402/404, "
-                "fused and fp8 forms 8/104; M <= 64: 8/104/108/208/216; M <= 128: 8/216)", name, M, tiles_per_wg, epilogue,
+                "fused and fp8 forms 8/104; M <= 64: 8/104/108/208/216/302/304/402; M <= 128: 8/216/302)", name, M,
+                tiles_per_wg, epilogue,
                 norm ? " + norm prologue" : "");
   return check_launch(name);
 }

@@ -515,10 +515,8 @@ KW_CODES = (302, 304, 308, 402, 404)   # K split across 2 / 4 / 8 waves of an 8-
 
 def tiled_slice_width(M: int, tiles_per_wg: int) -> int:
     """K slice of x a workgroup of linear_tiled stages at a time."""
-    if tiles_per_wg in KW_CODES:
-        return 512 if tiles_per_wg >= 400 else 1024
     mt = 1 if M <= 16 else 2 if M <= 32 else 4 if M <= 64 else 8
-    narrow = tiles_per_wg in (104, 108, 208)      # 216 (two tiles per wave, 8 waves) stages the wide slice
+    narrow = tiles_per_wg in (104, 108, 208, 402, 404)      # 216 (two tiles per wave, 8 waves) stages the wide slice
     return (512 if narrow else 1024) // (1 if mt <= 2 else mt // 2)
 
 
@@ -587,12 +585,12 @@ def linear_tiled_candidates(N: int, K: int, split_k: bool, M: int = 32, swiglu: 
         for g in ((1, 2, 4, 8) if split_k else (1,)):
             if g <= K // ksl and 64 <= wgs * g <= 1024 and (tiles, g) not in out:
                 out.append((tiles, g))
-    if M <= 32 and tiles_total < 8 * 160:
+    if tiles_total < 8 * 160:
         # few tiles (a tensor-parallel rank's slice): K split across the waves of a workgroup, the
         # only way to more waves when the output must be 16-bit or gated (no slabs)
         for tiles in KW_CODES:
             ksl = tiled_slice_width(M, tiles)
-            if K % ksl or (swiglu and tiles % 100 > 4):
+            if K % ksl or (swiglu and tiles % 100 > 4) or (tiles % 100) * 128 > ksl:   # a wave needs a register group of the slice
                 continue
             wgs = -(-tiles_total // tiles_per_workgroup(tiles))
             for g in ((1, 2, 4, 8) if split_k else (1,)):
