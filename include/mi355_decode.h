@@ -422,15 +422,16 @@ int32_t mi355_tile_weights(void* dst, const void* src, int32_t N, int32_t K,
  * workgroup with wide x slices, or 104 / 108 for the same with narrow slices (two
  * workgroups per CU); 208 / 216 (33..128 rows, epilogues 0-2): every wave streams two
  * adjacent tiles and uses each x fragment it reads from LDS for both -- 4 waves
- * with narrow slices / 8 waves with wide ones.  Slice width: 1024 (narrow 512) for M <= 32, halved for
+ * with narrow slices / 8 waves with wide ones; 210 / 212 / 214: 5 / 6 / 7 waves with wide slices
+ * (10 / 12 / 14 tiles per workgroup, for tile counts that 16 would spread over too few CUs).  Slice width: 1024 (narrow 512) for M <= 32, halved for
  * M <= 64 and again for M <= 128; K must be a multiple of it.  302 / 304 / 308 (epilogues 0-2,
  * 16-bit weights): workgroups of 8 waves in which 2 / 4 / 8 waves share a tile and
  * split its K range between them (partial sums added through LDS in wave order), for matrices
  * with few tiles -- the slices of a tensor-parallel rank -- whose output must be 16-bit or gated
  * and so cannot be split across workgroups; 402 / 404: the same with 512-wide slices (the SwiGLU
  * epilogue needs at most 4 waves per tile, and a wave at least 128 columns of the slice).  Built
- * geometries: M <= 32: 4, 8, 104, 108, 302, 304, 308, 402, 404; M <= 64: 8, 104, 108, 208, 216,
- * 302, 304, 402; M <= 128: 8, 216, 302.  k_groups (at most K / slice)
+ * geometries: M <= 32: 4, 8, 104, 108, 302, 304, 308, 402, 404; M <= 64: 8, 104, 108, 208, 210,
+ * 212, 214, 216, 302, 304, 402; M <= 128: 8, 210, 212, 214, 216, 302.  k_groups (at most K / slice)
  * splits K over workgroups; the slices are dealt to the groups as evenly as they
  * go, K / slice need not be a multiple of k_groups.
  *   epilogue 0: y = round(sum + bias)                       (k_groups == 1)

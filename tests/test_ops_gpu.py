@@ -928,7 +928,9 @@ def test_linear_tiled_norm_prologue(ops, dtype, M, H, N2, tiles, epi):
                                                 (128, 28672, 4096, 8, 1), (48, 4096, 1024, 104, 2),
                                                 (64, 4096, 4096, 108, 4), (40, 1000, 1024, 108, 1), (64, 4736, 3584, 108, 1),
                                                 (64, 4096, 4096, 208, 4), (40, 1000, 1024, 216, 1), (64, 4736, 3584, 208, 1),
-                                                (128, 4096, 14336, 216, 7), (100, 1544, 4096, 216, 8), (65, 336, 512, 216, 1)])
+                                                (128, 4096, 14336, 216, 7), (100, 1544, 4096, 216, 8), (65, 336, 512, 216, 1),
+                                                (64, 4736, 3584, 210, 1), (50, 1000, 1024, 212, 2), (33, 4096, 4096, 214, 4),
+                                                (128, 4096, 14336, 210, 7), (100, 1544, 4096, 212, 8), (65, 336, 512, 214, 1)])
 def test_linear_tiled_up_to_128_rows(ops, dtype, M, N, K, tiles, groups):
     """33..128 rows (more m-tiles per wave, narrower x slices): store, partial slabs and the
     in-launch reduction against the fp64 product; the reduction bit-identical to the slab sum."""
@@ -969,7 +971,7 @@ def test_linear_tiled_swiglu_epilogue_up_to_128_rows(ops, M, F, K):
     gu = ops.linear_tiled(xd, ops.tile_weights(dev(w, dtype)), 2 * F)
     np.testing.assert_array_equal(y, host(ops.silu_and_mul(gu)))
     # two tiles per wave: the wave holds the gate and the up tile itself; same sums, same bits
-    for tiles in ([208, 216] if M <= 64 else [216]):
+    for tiles in ([208, 210, 212, 214, 216] if M <= 64 else [210, 212, 214, 216]):
         if K % ops.tiled_slice_width(M, tiles) == 0:
             y2 = host(ops.linear_tiled(xd, wi, 2 * F, epilogue=ops.EPI_SILU_MUL, tiles_per_wg=tiles))
             np.testing.assert_array_equal(y2, y)
@@ -1121,7 +1123,9 @@ def test_tile_weights_fp8(ops, dtype, N, K, inter):
                                                      (128, 4608, 3584, 8, 7, True), (1, 64, 512, 104, 1, False),
                                                      (48, 6144, 4096, 8, 1, True), (64, 3584, 18944, 108, 8, False),
                                                      (48, 6144, 4096, 108, 1, True), (64, 3584, 18944, 208, 8, False),
-                                                     (48, 6144, 4096, 216, 1, True), (128, 4616, 3584, 216, 7, True)])
+                                                     (48, 6144, 4096, 216, 1, True), (128, 4616, 3584, 216, 7, True),
+                                                     (64, 3584, 18944, 210, 8, False), (48, 6144, 4096, 212, 1, True),
+                                                     (128, 4616, 3584, 214, 7, True)])
 def test_linear_tiled_w8(ops, dtype, M, N, K, tiles, groups, bias):
     rng = rng_for("w8", dtype, M, N, K)
     x, w = grid(rng, (M, K), dtype), grid(rng, (N, K), dtype, 0.05)
@@ -1158,6 +1162,10 @@ def test_linear_tiled_w8_swiglu(ops, M, F, K):
     q, s = ops.tile_weights_fp8(dev(w, dtype))
     gu = ops.linear_tiled_w8(xd, q, s, 2 * F)
     np.testing.assert_array_equal(y, host(ops.silu_and_mul(gu)))          # == the unfused HIP path
+    if M > 32:                                                            # two tiles per wave, 5 .. 8 waves: same sums, same bits
+        for tiles in (210, 212, 214, 216):
+            y2 = host(ops.linear_tiled_w8(xd, qi, si, 2 * F, epilogue=ops.EPI_SILU_MUL, tiles_per_wg=tiles))
+            np.testing.assert_array_equal(y2, y)
     q_ref, s_ref = R.quantize_rows_fp8(w)
     ref = R.silu_and_mul(R.linear_w8(x, q_ref, s_ref, None, dtype), dtype)
     diff = np.abs(y - ref)

@@ -11,8 +11,8 @@ SHAPES = [  # N, K, split_k: the projections of the benchmark models and of thei
     (1280, 8192, True), (8192, 1024, True), (7168, 8192, False), (16032, 4096, False), (1536, 4096, True),
 ]
 KW = {302, 304, 308, 402, 404}        # K split across the waves of a workgroup: up to 32 rows
-BUILT = {16: {4, 8, 104, 108} | KW, 32: {4, 8, 104, 108} | KW, 64: {8, 104, 108, 208, 216, 302, 304, 402},
-         128: {8, 216, 302}}
+BUILT = {16: {4, 8, 104, 108} | KW, 32: {4, 8, 104, 108} | KW,
+         64: {8, 104, 108, 208, 210, 212, 214, 216, 302, 304, 402}, 128: {8, 210, 212, 214, 216, 302}}
 
 
 @pytest.mark.parametrize("M", [1, 16, 17, 32, 33, 64, 65, 128])
@@ -30,7 +30,7 @@ def test_candidates_are_built_geometries(M, N, K, split):
         ksl = ops.tiled_slice_width(M, tiles)
         assert K % ksl == 0 and 1 <= groups <= min(K // ksl, 8)
         assert split or groups == 1
-        assert ops.tiles_per_workgroup(tiles) in ((1, 2, 4) if tiles in KW else (4, 8, 16))
+        assert ops.tiles_per_workgroup(tiles) in ((1, 2, 4) if tiles in KW else (4, 8, 10, 12, 14, 16))
 
 
 def test_narrow_slices_get_the_k_split_across_waves():
@@ -60,4 +60,7 @@ def test_slice_widths_and_workgroup_tiles():
     assert [ops.tiled_slice_width(m, 104) for m in (16, 32, 64, 128)] == [512, 512, 256, 128]
     assert ops.tiled_slice_width(64, 208) == 256 and ops.tiled_slice_width(64, 216) == 512
     assert ops.tiled_slice_width(128, 216) == 256
-    assert [ops.tiles_per_workgroup(t) for t in (4, 8, 104, 108, 208, 216)] == [4, 8, 4, 8, 8, 16]
+    assert [ops.tiles_per_workgroup(t) for t in (4, 8, 104, 108, 208, 210, 216)] == [4, 8, 4, 8, 8, 10, 16]
+    assert ops.tiled_slice_width(64, 210) == 512 and ops.tiled_slice_width(128, 214) == 256
+    # 2368 tiles (gate_up of Qwen2-7B): 16 per workgroup fill 148 CUs, 10 per workgroup 237
+    assert (210, 1) in ops.linear_tiled_candidates(37888, 3584, False, 64, swiglu=True)

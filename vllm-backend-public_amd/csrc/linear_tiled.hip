@@ -431,12 +431,15 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled2_kernel(
   const int tile0 = min(tile_raw, tiles_total - 1), tile1 = min(tile_raw + 1, tiles_total - 1);
   const int kgroup = blockIdx.y;
 
-  constexpr int NX = ROWS * (KSL / 8) / NT;
+  // 5..7 waves do not divide the slice's 16-byte vectors evenly: the last round's surplus threads
+  // repeat the slice's last vector (the same bytes to the same LDS address)
+  constexpr int NXV = ROWS * (KSL / 8);
+  constexpr int NX = (NXV + NT - 1) / NT;
   typedef unsigned int xvec __attribute__((ext_vector_type(4)));
   auto x_issue = [&](xvec (&xs)[NX], int p) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int v = i * NT + tid;
+      const int v = NXV % NT == 0 ? i * NT + tid : min(i * NT + tid, NXV - 1);
       const int row = v / (KSL / 8), col = v % (KSL / 8);
       xs[i] = MI355_LD(xvec, x, x + static_cast<int64_t>(min(row, M - 1)) * x_stride +
                                     static_cast<int64_t>(p) * KSL + col * 8);
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled2_kernel(
   auto x_commit = [&](xvec (&xs)[NX], int buf) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int v = i * NT + tid;
+      const int v = NXV % NT == 0 ? i * NT + tid : min(i * NT + tid, NXV - 1);
       const int row = v / (KSL / 8), col = v % (KSL / 8);
       *reinterpret_cast<xvec*>(&lds[buf * XBUF + row * ROWB + col * 16]) = xs[i];
     }
@@ -975,7 +978,7 @@ static bool launch_geometry(int mt, int nw, int ksl, int epi, bool norm, dim3 gr
   return false;
 }
 
-// Two tiles per wave (tiles_per_wg 208 / 216): epilogues 0-2, 16-bit or fp8 weights, 33..128 rows.
+// Two tiles per wave (tiles_per_wg 208 .. 216): epilogues 0-2, 16-bit or fp8 weights, 33..128 rows.
 template <typename T, int MT, int NW, int KSL>
 static bool launch_cfg2(int epi, dim3 grid, hipStream_t s, MI355_LT_PARAMS, const float* w_scale) {
 #define MI355_LT2(EPI_, W8_)                                                                                   \
@@ -1000,6 +1003,14 @@ static bool launch_geometry2(int mt, int nw, int ksl, int epi, dim3 grid, hipStr
   if (mt == 4 && nw == 4 && ksl == 256) return launch_cfg2<T, 4, 4, 256>(epi, grid, s, MI355_LT_ARGS, w_scale);
   if (mt == 4 && nw == 8 && ksl == 512) return launch_cfg2<T, 4, 8, 512>(epi, grid, s, MI355_LT_ARGS, w_scale);
   if (mt == 8 && nw == 8 && ksl == 256) return launch_cfg2<T, 8, 8, 256>(epi, grid, s, MI355_LT_ARGS, w_scale);
+  // 5 / 6 / 7 waves: for tile counts that 16 per workgroup would spread over too few CUs
+  // (2368 tiles: 148 workgroups of 16 tiles, 237 of 10)
+  if (mt == 4 && nw == 5 && ksl == 512) return launch_cfg2<T, 4, 5, 512>(epi, grid, s, MI355_LT_ARGS, w_scale);
+  if (mt == 4 && nw == 6 && ksl == 512) return launch_cfg2<T, 4, 6, 512>(epi, grid, s, MI355_LT_ARGS, w_scale);
+  if (mt == 4 && nw == 7 && ksl == 512) return launch_cfg2<T, 4, 7, 512>(epi, grid, s, MI355_LT_ARGS, w_scale);
+  if (mt == 8 && nw == 5 && ksl == 256) return launch_cfg2<T, 8, 5, 256>(epi, grid, s, MI355_LT_ARGS, w_scale);
+  if (mt == 8 && nw == 6 && ksl == 256) return launch_cfg2<T, 8, 6, 256>(epi, grid, s, MI355_LT_ARGS, w_scale);
+  if (mt == 8 && nw == 7 && ksl == 256) return launch_cfg2<T, 8, 7, 256>(epi, grid, s, MI355_LT_ARGS, w_scale);
   return false;
 }
 
@@ -1046,14 +1057,15 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
   // tiles_per_wg: 4 or 8 tiles (= waves) per workgroup; +100 selects the narrow x slice.  The slice is
   // 1024 (narrow: 512) wide up to 32 rows and halves with every doubling of the rows, so that the
   // double-buffered x image keeps its LDS footprint.
-  // 208 / 216: two tiles per wave (4 waves with the narrow slice / 8 waves with the wide one), 33..128 rows
-  const bool two = tiles_per_wg == 208 || tiles_per_wg == 216;
+  // 208 / 216: two tiles per wave (4 waves with the narrow slice / 8 waves with the wide one), 33..128 rows;
+  // 210 / 212 / 214: 5 / 6 / 7 waves with the wide slice
+  const bool two = tiles_per_wg >= 208 && tiles_per_wg <= 216 && tiles_per_wg % 2 == 0;
   // 302 / 304 / 308, 402 / 404: K split across 2 / 4 / 8 waves of an 8-wave workgroup (1024- / 512-wide slices)
   const bool kws = tiles_per_wg == 302 || tiles_per_wg == 304 || tiles_per_wg == 308 || tiles_per_wg == 402 ||
                    tiles_per_wg == 404;
   const int nw = two ? (tiles_per_wg - 200) / 2 : tiles_per_wg % 100;
   MI355_REQUIRE(two || kws || ((nw == 4 || nw == 8) && (tiles_per_wg == nw || tiles_per_wg == nw + 100)),
-                MI355_ERR_INVALID, "%s: tiles_per_wg must be 4, 8, 104, 108, 208, 216, 302, 304, 308, 402 or 404", name);
+                MI355_ERR_INVALID, "%s: tiles_per_wg must be 4, 8, 104, 108, 208-216 (even), 302, 304, 308, 402 or 404", name);
   const int mt = M <= 16 ? 1 : M <= 32 ? 2 : M <= 64 ? 4 : 8;
   const int ksl = ((kws ? tiles_per_wg >= 400 : two ? tiles_per_wg == 208 : tiles_per_wg >= 100) ? 512 : 1024) /
                   (mt <= 2 ? 1 : mt / 2);
@@ -1131,7 +1143,7 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
                                                     x_stride, y_stride, tiles_total, phases, fa);
   MI355_REQUIRE(ok, MI355_ERR_UNSUPPORTED,
                 "%s: no kernel for M %d with tiles_per_wg %d, epilogue %d%s (M <= 32: 4/8/104/108/302/304/308/402/404, "
-                "fused and fp8 forms 8/104; M <= 64: 8/104/108/208/216/302/304/402; M <= 128: 8/216/302)", name, M,
+                "fused and fp8 forms 8/104; M <= 64: 8/104/108/208-216/302/304/402; M <= 128: 8/210-216/302)", name, M,
                 tiles_per_wg, epilogue,
                 norm ? " + norm prologue" : "");
   return check_launch(name);

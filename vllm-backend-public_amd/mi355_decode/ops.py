@@ -516,16 +516,16 @@ KW_CODES = (302, 304, 308, 402, 404)   # K split across 2 / 4 / 8 waves of an 8-
 def tiled_slice_width(M: int, tiles_per_wg: int) -> int:
     """K slice of x a workgroup of linear_tiled stages at a time."""
     mt = 1 if M <= 16 else 2 if M <= 32 else 4 if M <= 64 else 8
-    narrow = tiles_per_wg in (104, 108, 208, 402, 404)      # 216 (two tiles per wave, 8 waves) stages the wide slice
+    narrow = tiles_per_wg in (104, 108, 208, 402, 404)      # 210 .. 216 (two tiles per wave, 5 .. 8 waves) stage the wide slice
     return (512 if narrow else 1024) // (1 if mt <= 2 else mt // 2)
 
 
 def tiles_per_workgroup(tiles_per_wg: int) -> int:
-    """Weight tiles one workgroup covers for a tiles_per_wg code (208 / 216: two tiles per wave;
+    """Weight tiles one workgroup covers for a tiles_per_wg code (208 .. 216: two tiles per wave;
     30x / 40x: 8 waves, x waves per tile)."""
     if tiles_per_wg in KW_CODES:
         return 8 // (tiles_per_wg % 100)
-    return {208: 8, 216: 16}.get(tiles_per_wg, tiles_per_wg % 100)
+    return tiles_per_wg % 100
 
 
 def plan_linear_tiled(N: int, K: int, split_k: bool, M: int = 32):
@@ -567,7 +567,8 @@ def linear_tiled_candidates(N: int, K: int, split_k: bool, M: int = 32, swiglu: 
     """Every (tiles_per_wg, k_groups) worth timing for linear_tiled on an [N, K] weight and M rows:
     both workgroup shapes that every kernel form (fp8, fused epilogues) is built for, K split into
     1, 2, 4 or 8 groups when the caller can take partial sums, beyond 32 rows also the forms with
-    two tiles per wave (208 / 216), kept if the launch has between 64 and 1024 workgroups; up to 32
+    two tiles per wave (208 .. 216: 4 .. 8 waves, so that a tile count that 16 per workgroup would
+    spread over too few CUs finds a better deal), kept if the launch has between 64 and 1024 workgroups; up to 32
     rows and few tiles also the forms that split K across the waves of a workgroup (`swiglu`: the
     gate / up pair must share a workgroup, at most 4 waves per tile).  Not
     every form exists for every code (fp8 at up to 32 rows: 8 and 104 only): the caller skips a
@@ -577,7 +578,8 @@ def linear_tiled_candidates(N: int, K: int, split_k: bool, M: int = 32, swiglu: 
         return []
     out = [first]
     tiles_total = (N + 15) // 16
-    for tiles in ((8, 104, 108) if M <= 32 else (8, 104, 108, 208, 216) if M <= 64 else (8, 216)):
+    for tiles in ((8, 104, 108) if M <= 32 else (8, 104, 108, 208, 216, 210, 212, 214) if M <= 64
+                  else (8, 216, 210, 212, 214)):
         ksl = tiled_slice_width(M, tiles)
         if K % ksl:
             continue
