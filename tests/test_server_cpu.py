@@ -115,7 +115,8 @@ def test_errors_are_openai_style_json():
     th, c, _, _ = make()
     th.ready.wait(10)
     for body, code in [({"max_tokens": 3}, 400), ({"prompt": [1], "model": "other"}, 404),
-                       ({"prompt": [1], "n": 2}, 400), ({"prompt": [V + 5]}, 400), ({"prompt": []}, 400),
+                       ({"prompt": [1], "n": 0}, 400), ({"prompt": [1], "n": 2, "best_of": 4}, 400),
+                       ({"prompt": [[1], [2]], "n": 200}, 400), ({"prompt": [V + 5]}, 400), ({"prompt": []}, 400),
                        ({"prompt": list(range(600))}, 400), ({"prompt": [1], "max_tokens": 0}, 400),
                        ({"prompt": [1], "temperature": -1}, 400), ({"prompt": [1], "top_p": 0}, 400),
                        ({"prompt": [1], "logprobs": 50}, 400)]:
@@ -135,6 +136,38 @@ def test_sampling_parameters_are_accepted():
     assert r.status_code == 200 and r.json()["usage"]["completion_tokens"] == 3
     s = th.engine.runner.last_sampling
     assert s is not None and s["seeds"].tolist() == [11] and s["top_k"].tolist() == [20]
+    th.shutdown()
+
+
+def test_n_completions_per_prompt():
+    """n > 1: n sequences per prompt, choices numbered prompt-major, the prompt counted once, copy j
+    drawing from seed + j; streamed chunks carry the choice index."""
+    th, c, _, tok = make()
+    th.ready.wait(10)
+    r = c.post("/v1/completions", json={"prompt": [[5, 6, 7], [8, 9]], "max_tokens": 4, "temperature": 0, "n": 3})
+    assert r.status_code == 200, r.text
+    chs = sorted(r.json()["choices"], key=lambda x: x["index"])
+    assert [ch["index"] for ch in chs] == list(range(6))
+    for ch in chs:
+        assert ch["text"] == tok.decode(reference([[5, 6, 7], [8, 9]][ch["index"] // 3], 4))
+    assert r.json()["usage"] == {"prompt_tokens": 5, "completion_tokens": 24, "total_tokens": 29}
+    seeds = []
+    orig = th.engine.add_request
+
+    def spy(rid, prompt, params, **kw):
+        seeds.append(params.seed)
+        return orig(rid, prompt, params, **kw)
+
+    th.engine.add_request = spy
+    r = c.post("/v1/completions", json={"prompt": [1, 2], "max_tokens": 2, "temperature": 0.7, "seed": 40, "n": 3,
+                                        "best_of": 3})
+    assert r.status_code == 200 and len(r.json()["choices"]) == 3 and sorted(seeds) == [40, 41, 42]
+    with c.stream("POST", "/v1/completions", json={"prompt": [9, 8, 7], "max_tokens": 3, "temperature": 0, "n": 2,
+                                                   "stream": True}) as r:
+        chunks = [json.loads(ln[6:]) for ln in r.iter_lines() if ln.startswith("data: {")]
+    for i in (0, 1):
+        mine = [ch["choices"][0] for ch in chunks if ch["choices"][0]["index"] == i]
+        assert "".join(m["text"] for m in mine) == tok.decode(reference([9, 8, 7], 3)) and mine[-1]["finish_reason"] == "length"
     th.shutdown()
 
 

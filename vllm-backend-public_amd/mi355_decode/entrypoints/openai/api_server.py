@@ -20,6 +20,7 @@ CrashLoopBackOff and the harness counts a failure (vllm_manager.py:921-936).
 from __future__ import annotations
 
 import asyncio
+import dataclasses
 import json
 import logging
 import os
@@ -32,6 +33,9 @@ from fastapi import FastAPI, Request
 from fastapi.responses import JSONResponse, Response, StreamingResponse
 
 from ..cli_args import parse_args, sanitize_env
+
+MAX_N = 64           # completions per prompt
+MAX_CHOICES = 256    # completions per request (prompts x n)
 
 log = logging.getLogger("mi355_decode")
 
@@ -177,9 +181,18 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
         if model != served_model_name:
             return _error(404, f"The model `{model}` does not exist.", "NotFoundError")
         try:
-            prompts = normalise_prompts(body["prompt"], tokenizer, vocab_size)
-            if body.get("n", 1) != 1 or body.get("best_of", 1) not in (None, 1):
-                raise ValueError("n > 1 / best_of > 1 are not supported")
+            base_prompts = normalise_prompts(body["prompt"], tokenizer, vocab_size)
+            # n completions per prompt: n independent sequences (choice index = prompt index * n + j, as the
+            # engine this replaces numbers them); with a seed, copy j draws from seed + j
+            n = body.get("n", 1)
+            n = 1 if n is None else n
+            if isinstance(n, bool) or not isinstance(n, int) or n < 1 or n > MAX_N:
+                raise ValueError(f"n must be an integer in [1, {MAX_N}]")
+            if body.get("best_of") not in (None, n):
+                raise ValueError("best_of other than n is not supported")
+            if n * len(base_prompts) > MAX_CHOICES:
+                raise ValueError(f"at most {MAX_CHOICES} completions per request (prompts x n)")
+            prompts = [p for p in base_prompts for _ in range(n)]
             want_lp = body.get("logprobs")
             want_lp = None if want_lp is None or want_lp is False else int(want_lp)
             # echo + logprobs: the prompt is scored too (how evaluation harnesses compute log-likelihoods)
@@ -195,6 +208,10 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
                 stop_token_ids=list(body.get("stop_token_ids") or []),
                 ignore_eos=bool(body.get("ignore_eos", False)), logprobs=want_lp,
                 prompt_logprobs=prompt_lp)
+            if n > 1 and params.seed is not None:
+                copies = [dataclasses.replace(params, seed=int(params.seed) + j) for j in range(n)]
+            else:
+                copies = [params] * n
             if params.top_k > 1024:
                 raise ValueError("top_k above 1024 is not supported: sampling draws from at most the 1024 most likely "
                                  "tokens (top_k <= 0 means those 1024)")
@@ -217,7 +234,7 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
         rids = [f"{cmpl_id}-{i}" for i in range(len(prompts))]
         for i, (rid, p) in enumerate(zip(rids, prompts)):
             # the sink runs on this request's loop; a step's outputs for one loop arrive in one wake-up
-            engine_thread.submit(rid, p, params, lambda o, i=i: q.put_nowait((i, o)), loop=loop)
+            engine_thread.submit(rid, p, copies[i % n], lambda o, i=i: q.put_nowait((i, o)), loop=loop)
 
         detoks = [IncrementalDetokenizer(tokenizer) for _ in prompts]
         texts = [tokenizer.decode(p) if echo else "" for p in prompts]
@@ -288,8 +305,9 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
                 sent[i] = len(texts[i])
                 yield i, delta, reasons[i], step_lp
 
-        usage = lambda: {"prompt_tokens": sum(len(p) for p in prompts), "completion_tokens": sum(n_out),  # noqa: E731
-                         "total_tokens": sum(len(p) for p in prompts) + sum(n_out)}
+        # a prompt counts once, however many completions it gets
+        usage = lambda: {"prompt_tokens": sum(len(p) for p in base_prompts), "completion_tokens": sum(n_out),  # noqa: E731
+                         "total_tokens": sum(len(p) for p in base_prompts) + sum(n_out)}
 
         started = [False] * len(prompts)
         if stream:
