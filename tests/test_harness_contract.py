@@ -169,3 +169,30 @@ def test_engine_plugin_processor_matches_the_reference_vllm_processor():
     assert nov == g["no_vllm_section"]
     tp = Mi355Processor(g["eval_url"], gpus=4).process_yaml_data(copy.deepcopy(g["base"]), "a/b", "r", "e", "m", "1")
     assert tp["vllm"]["vllm"]["tensor_parallel_size"] == 4 and tp["vllm"]["resources"]["limits"][GPU_RESOURCE] == 4
+
+
+def test_deploy_values_files_start_this_server():
+    """deploy/values-*.yaml (Helm custom values for the harness's chart) name an image, AMD GPUs matching the
+    tensor-parallel degree, and `args` this server's CLI takes without a leftover; the Dockerfile copies
+    directories that exist and starts the server module."""
+    import glob
+    import os
+    import yaml
+    from mi355_decode.entrypoints.cli_args import parse_args
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "deploy", "values-*.yaml")))
+    assert len(files) >= 4
+    for f in files:
+        v = yaml.safe_load(open(f))
+        assert set(v) >= {"image", "args", "resources"} and v["image"]["repository"] and v["image"]["tag"]
+        ns, ea = parse_args([str(a) for a in v["args"]])
+        assert ea.model.startswith("/") and ea.dtype == "bfloat16" and ns.port == 8000
+        gpus = v["resources"]["limits"]["amd.com/gpu"]
+        assert gpus == v["resources"]["requests"]["amd.com/gpu"] == ea.tensor_parallel_size
+        assert ea.max_num_seqs in (16, 32, 64, 128) and ea.max_model_len >= 256
+        assert ("fp8" in f) == (ea.quantization == "fp8")
+    docker = open(os.path.join(root, "deploy", "Dockerfile")).read()
+    for line in docker.splitlines():
+        if line.startswith("COPY "):
+            assert os.path.isdir(os.path.join(root, line.split()[1])), line
+    assert "mi355_decode.entrypoints.openai.api_server" in docker and "HSA_ENABLE_IPC_MODE_LEGACY=0" in docker
