@@ -554,6 +554,33 @@ int32_t mi355_linear_tiled_w8(void* y, int64_t y_stride, void* partial,
                               int32_t epilogue, int32_t dtype, void* stream);
 
 /*
+ * W8A8: the same fp8 weight copies multiplied with fp8 ACTIVATIONS on the fp8 matrix
+ * instruction (--quantization fp8 in the engine this replaces quantises activations per
+ * token too; vllm_manager.py:405-407, vllm_templates.py:75-76 pass the flag through).
+ * mi355_quant_rows_fp8 turns 16-bit rows x[M, K] (K % 8 == 0) into row-major e4m3fn rows
+ * xq (xq_stride bytes per row, a multiple of 8) and one fp32 scale per row with the recipe
+ * of the weight copies: scale = max|row| / 448 (1 for an all-zero row), q = fp8_rne(x / scale).
+ * mi355_linear_tiled_w8a8 computes
+ *   y[m, n] = round(((sum_k xq[m, k] q[n, k]) * w_scale[n]) * x_scale[m] (+ bias[n]))
+ * with fp32 accumulation; dtype is the type of y and bias.  M <= 128; xq 16-byte aligned with
+ * xq_stride a multiple of 16; tiles_per_wg 208 / 210 / 212 / 214 / 216: every wave streams two
+ * adjacent weight tiles, 4 (narrow x slices) / 5 / 6 / 7 / 8 waves per workgroup; x slice = 1024
+ * (208: 512) columns for M <= 32, halved for M <= 64 and again for M <= 128, K a multiple of
+ * it.  Built geometries: M <= 32: 208, 216; M <= 64: all five; M <= 128: 210 .. 216.
+ * Epilogues 0-2 and k_groups as mi355_linear_tiled (the slabs of epilogue 2 carry both scales).
+ * Not used by the decode step of the engine, which keeps 16-bit activations.
+ */
+int32_t mi355_quant_rows_fp8(void* xq, int64_t xq_stride, float* scale, const void* x,
+                             int64_t x_stride, int32_t M, int32_t K, int32_t dtype,
+                             void* stream);
+int32_t mi355_linear_tiled_w8a8(void* y, int64_t y_stride, void* partial, const void* xq,
+                                int64_t xq_stride, const float* x_scale,
+                                const void* w_tiled_fp8, const float* w_scale,
+                                const void* bias, int32_t M, int32_t N, int32_t K,
+                                int32_t tiles_per_wg, int32_t k_groups, int32_t epilogue,
+                                int32_t dtype, void* stream);
+
+/*
  * One-shot all-reduce (sum, in place) of the small 16-bit messages of a tensor-parallel decode
  * step: the [tokens, hidden] partial sums after the attention output projection (and after the
  * down projection when the MLP is sharded), one process per GPU.  Every rank writes its message

@@ -1192,6 +1192,131 @@ def test_linear_tiled_w8_decodes_every_fp8_code_exactly(ops, dtype):
         np.testing.assert_array_equal(y, w[:, k0:k0 + 32].T)
 
 
+# --------------------------------------------------------------------------- #
+# W8A8: fp8 activations x fp8 weights on the fp8 matrix instruction
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,K,pad", [(1, 8, 0), (5, 1000, 24), (64, 3584, 0), (128, 18944, 0), (33, 4096, 64)])
+def test_quant_rows_fp8(ops, dtype, M, K, pad):
+    """Activation rows -> e4m3fn codes + one scale per row: the codes decode to the oracle's values
+    bit for bit, the scales are the oracle's; an all-zero row gets scale 1; strided inputs."""
+    rng = rng_for("quant-rows", dtype, M, K)
+    x = grid(rng, (M, K + pad), dtype, 3.0)
+    if M > 2:
+        x[1] = 0.0
+        x[2, : K // 2] *= 1e-3                                       # subnormal codes after scaling
+        x = R.round_to(x, dtype)
+    xd = dev(x, dtype)[:, :K]
+    xq, sc = ops.quant_rows_fp8(xd)
+    q_ref, s_ref = R.quantize_rows_fp8(x[:, :K])
+    np.testing.assert_array_equal(sc.cpu().numpy(), s_ref)
+    got = R.fp8_e4m3fn_decode_table()[xq.cpu().numpy()]
+    np.testing.assert_array_equal(got, q_ref)
+    np.testing.assert_array_equal(np.signbit(got), np.signbit(q_ref))
+    if M > 2:
+        assert sc[1].item() == 1.0 and not xq[1].any()
+
+
+@pytest.mark.parametrize("M,tiles", [(16, 208), (32, 216), (64, 208), (64, 210), (64, 216), (128, 212), (128, 216)])
+def test_linear_tiled_w8a8_operand_order_is_exact_on_integers(ops, M, tiles):
+    """Integer-valued fp8 operands (every product and sum exact in fp32), asymmetric, both scales 1:
+    the fp32 slabs equal the integer product exactly -- pins the lane / k order of both operands of the
+    fp8 instruction, the k-step pairing of the weight blocks and the row / column order of the result."""
+    rng = rng_for("w8a8-int", M, tiles)
+    N, K = 208, 2048
+    x = rng.integers(-8, 9, (M, K)).astype(np.float32)
+    w = rng.integers(-8, 9, (N, K)).astype(np.float32)
+    x[:, 5] = 448.0                                                  # row scales exactly 1
+    w[np.arange(N), (7 * np.arange(N)) % K] = 448.0
+    xq, sx = ops.quant_rows_fp8(dev(x, "bfloat16"))
+    q, sw = ops.tile_weights_fp8(dev(w, "bfloat16"))
+    assert (sx.cpu().numpy() == 1).all() and (sw.cpu().numpy()[:N] == 1).all()
+    ref = x.astype(np.float64) @ w.astype(np.float64).T
+    assert np.abs(ref).max() < 2 ** 24
+    for groups in (1, 2):
+        part = ops.linear_tiled_w8a8(xq, sx, q, sw, N, k_groups=groups, epilogue=ops.EPI_PARTIAL,
+                                     tiles_per_wg=tiles).cpu().numpy()
+        np.testing.assert_array_equal(part.astype(np.float64).sum(axis=0), ref)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,N,K,tiles,groups,bias", [(64, 3584, 18944, 208, 8, False), (64, 4608, 3584, 210, 7, True),
+                                                     (48, 6144, 4096, 212, 1, True), (128, 4616, 3584, 214, 7, True),
+                                                     (32, 4096, 4096, 216, 4, False), (7, 1000, 1024, 208, 1, True),
+                                                     (100, 1544, 4096, 216, 8, False), (1, 64, 1024, 216, 1, False)])
+def test_linear_tiled_w8a8(ops, dtype, M, N, K, tiles, groups, bias):
+    rng = rng_for("w8a8", dtype, M, N, K)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (N, K), dtype, 0.05)
+    b = grid(rng, (N,), dtype) if bias else None
+    q, sw = ops.tile_weights_fp8(dev(w, dtype))
+    xq, sx = ops.quant_rows_fp8(dev(x, dtype))
+    q_ref, sw_ref = R.quantize_rows_fp8(w)
+    xq_ref, sx_ref = R.quantize_rows_fp8(x)
+    ref = R.linear_w8a8(xq_ref, sx_ref, q_ref, sw_ref, b, dtype)
+    ref64 = (xq_ref.astype(np.float64) @ q_ref.astype(np.float64).T) * sw_ref[None, :].astype(np.float64) * \
+        sx_ref[:, None].astype(np.float64)
+    if bias:
+        ref64 = ref64 + b.astype(np.float64)
+    tol = _linear_tol(ref64, xq_ref * sx_ref[:, None], q_ref * sw_ref[:, None], K, dtype)
+    bd = dev(b, dtype) if bias else None
+    # rounding flips against the oracle: it sums in float64, the device in fp32 over K products of magnitude up
+    # to 448^2 -- ~1e-5 relative on the sum, a visible fraction of an fp16 ulp at K = 18944
+    flips = 0.02 if dtype == "bfloat16" else 0.10
+    if groups == 1:
+        y = host(ops.linear_tiled_w8a8(xq, sx, q, sw, N, dtype=DT[dtype], bias=bd, tiles_per_wg=tiles))
+        assert (np.abs(y - ref64) <= tol).all(), f"max err {np.abs(y - ref64).max()}"
+        assert (y != ref).mean() <= flips
+    part = ops.linear_tiled_w8a8(xq, sx, q, sw, N, k_groups=groups, epilogue=ops.EPI_PARTIAL, tiles_per_wg=tiles).cpu().numpy()
+    y = _slab_sum(part, b, dtype)
+    assert (np.abs(y - ref64) <= tol).all(), f"max err {np.abs(y - ref64).max()}"
+    assert (y != ref).mean() <= flips
+    # what 8-bit activations cost on top of 8-bit weights, against the unquantised product
+    full = x.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
+    assert np.abs(y - full).max() <= 0.08 * np.abs(full).max() + 0.08
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,F,K", [(64, 18944, 3584), (128, 2048, 1024), (20, 512, 1024)])
+def test_linear_tiled_w8a8_swiglu(ops, dtype, M, F, K):
+    """The SwiGLU epilogue on the interleaved matrix == the store epilogue + the SwiGLU kernel, bit for bit,
+    for every workgroup shape; and close to the oracle's composition."""
+    rng = rng_for("w8a8-silu", dtype, M, F, K)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (2 * F, K), dtype, 0.05)
+    xq, sx = ops.quant_rows_fp8(dev(x, dtype))
+    q, s = ops.tile_weights_fp8(dev(w, dtype))
+    qi, si = ops.tile_weights_fp8(dev(w, dtype), interleave_halves=True)
+    gu = ops.linear_tiled_w8a8(xq, sx, q, s, 2 * F, dtype=DT[dtype])
+    want = host(ops.silu_and_mul(gu))
+    for tiles in ([208, 216] if M <= 32 else [208, 210, 212, 214, 216] if M <= 64 else [210, 212, 214, 216]):
+        y = host(ops.linear_tiled_w8a8(xq, sx, qi, si, 2 * F, dtype=DT[dtype], epilogue=ops.EPI_SILU_MUL, tiles_per_wg=tiles))
+        np.testing.assert_array_equal(y, want)
+    q_ref, s_ref = R.quantize_rows_fp8(w)
+    xq_ref, sx_ref = R.quantize_rows_fp8(x)
+    # against the oracle (float64 sums): a flipped rounding of gate and of up, each amplified by the gate's
+    # slope, plus the roundings of silu and of the product
+    gu_ref = R.linear_w8a8(xq_ref, sx_ref, q_ref, s_ref, None, dtype)
+    ref = R.silu_and_mul(gu_ref, dtype)
+    diff = np.abs(want - ref)
+    # absolute part: the fp32 accumulation error of gate / up (the _linear_tol term), times the other factor
+    acc_err = 1e-5 * np.sqrt(K) * np.abs(x).max() * np.abs(w).max()
+    atol = acc_err * (2 * np.abs(gu_ref).max() + 1) + 6 * ULP[dtype] * 1e-2
+    assert (diff <= 6 * ULP[dtype] * np.abs(ref) + atol).all(), (diff - 6 * ULP[dtype] * np.abs(ref)).max() / atol
+    assert (want != ref).mean() <= (0.05 if dtype == "bfloat16" else 0.15)
+
+
+def test_linear_tiled_w8a8_rejects_what_it_does_not_build(ops):
+    from mi355_decode._lib import Mi355Error
+    x = torch.zeros(128, 1024, dtype=torch.bfloat16, device="cuda")
+    xq, sx = ops.quant_rows_fp8(x)
+    q, s = ops.tile_weights_fp8(torch.zeros(64, 1024, dtype=torch.bfloat16, device="cuda"))
+    with pytest.raises(Mi355Error, match="tiles_per_wg must be"):
+        ops.linear_tiled_w8a8(xq, sx, q, s, 64, tiles_per_wg=8)
+    with pytest.raises(Mi355Error, match="no kernel for M 128"):
+        ops.linear_tiled_w8a8(xq, sx, q, s, 64, tiles_per_wg=208)
+    with pytest.raises(Mi355Error, match="partial-sum epilogue"):
+        ops.linear_tiled_w8a8(xq, sx, q, s, 64, tiles_per_wg=216, k_groups=2)
+
+
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 @pytest.mark.parametrize("M,F,K", [(128, 14336, 4096), (64, 2048, 1024)])
 def test_linear_tiled_w8_swiglu_fused_equals_unfused_at_more_rows(ops, dtype, M, F, K):

@@ -68,6 +68,8 @@ def _load() -> ctypes.CDLL:
         "mi355_tiled_weight_fp8_bytes": (I64, [I32, I32]),
         "mi355_tile_weights_fp8": (I32, [P, P, P, I32, I32, I32, I32, P]),
         "mi355_linear_tiled_w8": (I32, [P, I64, P, P, I64, P, P, P, I32, I32, I32, I32, I32, I32, I32, P]),
+        "mi355_quant_rows_fp8": (I32, [P, I64, P, P, I64, I32, I32, I32, P]),
+        "mi355_linear_tiled_w8a8": (I32, [P, I64, P, P, I64, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, P]),
         "mi355_paged_attn_decode_fused": (I32, [P, P, I64, P, I32, I64, P, P, I32, P, P, P, I32, P, I32, P, I32, I32,
                                                 I32, I32, F, I32, P, I64, I32, P]),
         "mi355_linear_tiled_fused": (I32, [P, I64, P, P, I64, P, P, I32, I32, I32, I32, I32, I32, P, P, I32, F, P, I64,
@@ -106,6 +108,7 @@ EXPORTS = ("mi355_abi_version", "mi355_last_error", "mi355_target_arch",
            "mi355_fused_add_rms_norm_partial", "mi355_rope_kv_write_partial",
            "mi355_linear_tiled_fused", "mi355_paged_attn_decode_fused",
            "mi355_tiled_weight_fp8_bytes", "mi355_tile_weights_fp8", "mi355_linear_tiled_w8",
+           "mi355_quant_rows_fp8", "mi355_linear_tiled_w8a8",
            "mi355_token_logprobs",
            "mi355_allreduce_oneshot_handle_bytes", "mi355_allreduce_oneshot_init", "mi355_allreduce_oneshot_connect",
            "mi355_allreduce_oneshot_run", "mi355_allreduce_oneshot_status", "mi355_allreduce_oneshot_destroy")

@@ -758,3 +758,63 @@ def linear_tiled_w8(x: torch.Tensor, w_fp8: torch.Tensor, w_scale: torch.Tensor,
                                     w_scale.data_ptr(), bias.data_ptr() if bias is not None else 0, M, N, K,
                                     tiles_per_wg, k_groups, epilogue, dt, _stream()))
     return ret
+
+
+def quant_rows_fp8(x: torch.Tensor, out: torch.Tensor | None = None, scale: torch.Tensor | None = None):
+    """16-bit rows [M, K] -> (e4m3fn rows as uint8 [M, K], one fp32 scale per row): the activation
+    input of linear_tiled_w8a8."""
+    dt = _dt16(x, "x")
+    M, K = x.shape
+    if out is None:
+        out = torch.empty((M, K), dtype=torch.uint8, device=x.device)
+    elif out.dtype != torch.uint8 or tuple(out.shape) != (M, K):
+        raise ValueError("out must be uint8 [M, K]")
+    if scale is None:
+        scale = torch.empty(M, dtype=torch.float32, device=x.device)
+    elif scale.dtype != torch.float32 or scale.numel() != M or not scale.is_contiguous():
+        raise ValueError("scale must be contiguous float32 [M]")
+    check(lib.mi355_quant_rows_fp8(out.data_ptr(), _rows(out, "out"), scale.data_ptr(), x.data_ptr(), _rows(x, "x"),
+                                   M, K, dt, _stream()))
+    return out, scale
+
+
+def linear_tiled_w8a8(xq: torch.Tensor, x_scale: torch.Tensor, w_fp8: torch.Tensor, w_scale: torch.Tensor, N: int,
+                      dtype: torch.dtype = torch.bfloat16, bias: torch.Tensor | None = None,
+                      out: torch.Tensor | None = None, partial: torch.Tensor | None = None, tiles_per_wg: int = 0,
+                      k_groups: int = 1, epilogue: int = EPI_STORE):
+    """fp8 activations (quant_rows_fp8) x fp8 weights (tile_weights_fp8) on the fp8 matrix instruction;
+    `dtype`: the 16-bit type of the output and the bias.  M <= 128."""
+    _dev(xq, "xq"), _dev(x_scale, "x_scale"), _dev(w_fp8, "w_fp8"), _dev(w_scale, "w_scale")
+    if xq.dtype != torch.uint8 or xq.dim() != 2:
+        raise ValueError("xq must be uint8 [M, K]")
+    M, K = xq.shape
+    dt = _DT.get(dtype)
+    if dt is None:
+        raise ValueError("dtype must be bfloat16 or float16")
+    if x_scale.dtype != torch.float32 or x_scale.numel() != M or not x_scale.is_contiguous():
+        raise ValueError("x_scale must be contiguous float32 [M]")
+    if w_fp8.dtype != torch.uint8 or w_fp8.numel() != int(lib.mi355_tiled_weight_fp8_bytes(N, K)):
+        raise ValueError("w_fp8 does not match (N, K)")
+    if w_scale.dtype != torch.float32 or w_scale.numel() != (N + 15) // 16 * 16 or not w_scale.is_contiguous():
+        raise ValueError("w_scale must be contiguous float32 [ceil(N/16)*16]")
+    if tiles_per_wg == 0:
+        tiles_per_wg = 216 if M <= 32 or -(-((N + 15) // 16) // 16) * k_groups >= 200 else 210
+    y_ptr = p_ptr = y_stride = 0
+    if epilogue == EPI_PARTIAL:
+        if partial is None:
+            partial = torch.empty((k_groups, M, N), dtype=torch.float32, device=xq.device)
+        _check_partial(partial, k_groups, M, N)
+        p_ptr, ret = partial.data_ptr(), partial
+    else:
+        width = N // 2 if epilogue == EPI_SILU_MUL else N
+        if out is None:
+            out = torch.empty((M, width), dtype=dtype, device=xq.device)
+        elif out.dtype != dtype or tuple(out.shape) != (M, width):
+            raise ValueError(f"out must be [M, {width}] in `dtype`")
+        y_ptr, y_stride, ret = out.data_ptr(), _rows(out, "out"), out
+    if bias is not None and (bias.dtype != dtype or bias.numel() != N or not bias.is_contiguous()):
+        raise ValueError("bias must be contiguous [N] in `dtype`")
+    check(lib.mi355_linear_tiled_w8a8(y_ptr, y_stride, p_ptr, xq.data_ptr(), _rows(xq, "xq"), x_scale.data_ptr(),
+                                      w_fp8.data_ptr(), w_scale.data_ptr(), bias.data_ptr() if bias is not None else 0,
+                                      M, N, K, tiles_per_wg, k_groups, epilogue, dt, _stream()))
+    return ret
