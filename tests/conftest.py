@@ -20,7 +20,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # largest allocations and the widest kernels) after them, the allocation-free entry point last.
 # With `-x` one failing file then cannot hide the parity results of the files before it.
 GPU_ORDER = ("test_ops_gpu", "test_model_gpu", "test_tp_gpu", "test_plumbing_gpu", "test_configs_gpu",
-             "test_allreduce_gpu", "test_bounds_gpu")
+             "test_allreduce_gpu", "test_rccl_gpu", "test_bounds_gpu")
 _fault_log = None
 
 
