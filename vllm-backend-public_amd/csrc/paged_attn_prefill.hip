@@ -11,18 +11,21 @@
 // in FRAGMENT ORDER -- piece (fragment, lane) at (fragment*64 + lane)*16, so every wave's
 // `ds_read_b128` of an MFMA A operand is lane-linear and conflict-free -- while the waves
 // compute on the other buffer; one workgroup barrier per step.  The query fragments (B
-// operands) sit in LDS as well.  Softmax in two passes over the keys: the first finds every
-// column's maximum score (QK^T MFMAs only), the second forms p = exp2(s*scale - max) and
-// O += V^T P^T with no rescaling -- the loop bodies are straight lines, O never leaves the
-// accumulation registers, and the QK^T MFMAs are paid twice (an online softmax with 16 columns
-// per tile moves its running maximum in most steps; every move rescales all of O, and the
-// compiler then shuttled the 128 registers of O between register files at EVERY step).
+// operands) stay in registers.  Softmax in ONE pass over the keys with a LAZILY updated exponent
+// reference: p = exp2(s*scale - m_ref), where m_ref is a column's maximum as of the last time
+// it was brought up to date.  A step only checks, lane by lane and with no cross-lane traffic,
+// whether any of its scores exceeds m_ref + 8; only then (a wave-uniform, rarely taken branch:
+// the first step of a tile and the few steps in which a maximum jumps by more than 2^8) are the
+// column maxima reduced across lanes and O and l rescaled.  In between p <= 2^8, harmless in the
+// 16-bit P operand and in the fp32 sums, and the loop body is a straight line: scores, one fma +
+// exp2 per score, PV.  (An online softmax that follows the true maximum moves it in most steps
+// with 16 columns per tile, and every move rescales all of O; a two-pass form -- maxima first --
+// pays the QK^T MFMAs, the K staging and the barriers twice: 1.5x slower than this one.)
 //
 // MFMA mapping is the decode kernel's (paged_attn_decode.hip): S^T = K . Q^T with the K
 // rows as the A operand, and O^T += V^T . P^T with the transposed V page as the A operand
 // and the lane's own probabilities as B.  The causal mask is applied per column (key <=
-// position of the column's query).  Latency-bound at 1-2 workgroups per CU: measured 326
-// TFLOP/s on 16 x 2048 tokens (13 % of the bf16 MFMA peak).
+// position of the column's query).
 #include "common.h"
 
 #include <math.h>
@@ -34,8 +37,10 @@ namespace mi355 {
 constexpr int kPrefillThreads = 256;
 constexpr int kPrefillWaves = kPrefillThreads / 64;
 
+// Second launch bound: waves per SIMD the register allocation must leave room for.  Two workgroups
+// per CU overlap each other's dependent chains (LDS reads -> MFMAs -> exp2 -> MFMAs -> barrier).
 template <typename T, int D, int NQ>
-__global__ __launch_bounds__(kPrefillThreads) void paged_attn_prefill_kernel(
+__global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_prefill_kernel(
     uint16_t* __restrict__ out, int64_t out_stride, const uint16_t* __restrict__ q, int64_t q_stride,
     const uint16_t* __restrict__ k_cache, const uint16_t* __restrict__ v_cache, int num_blocks,
     const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ cu_seqlens,
@@ -53,10 +58,7 @@ __global__ __launch_bounds__(kPrefillThreads) void paged_attn_prefill_kernel(
   constexpr int PIECES = 8 * D;                  // 16-byte pieces per step: two K pages + two V pages
   constexpr int PPT = PIECES / kPrefillThreads;  // per thread: 4 (D = 128) or 2 (D = 64)
   static_assert(PIECES % kPrefillThreads == 0, "whole pieces per thread");
-  // the wave's query fragments (B operands) live in LDS too, [wave][column tile][k-step][lane][16 B]:
-  // 16 KB per wave at NQ = 4 would otherwise be 64 registers per lane on top of the 128 of O
-  constexpr int QBYTES = kPrefillWaves * NQ * KS * 1024;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + QBYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
 
   const int qtile = blockIdx.x, kvh = blockIdx.y, seq = blockIdx.z;
   const int group = num_heads / num_kv_heads;
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(kPrefillThreads) void paged_attn_prefill_kernel(
   // this lane's columns: pair index p = (wave*NQ + t)*16 + c -> (query, head)
   int col_q[NQ], col_head[NQ], col_pos[NQ];
   bool col_ok[NQ];
-  unsigned char* qlds = &lds[2 * BUF + wave * (NQ * KS * 1024) + lane * 16];   // this lane's slot of fragment 0
+  uint4 qf[NQ][KS];                              // the lane's query fragments (B operands), read once
 #pragma unroll
   for (int t = 0; t < NQ; ++t) {
     const int p = (wave * NQ + t) * 16 + c;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(kPrefillThreads) void paged_attn_prefill_kernel(
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const uint4 v = MI355_LD(uint4, q, qp + 32 * ks);     // always a valid row; dropped if not ours
-      *reinterpret_cast<uint4*>(qlds + (t * KS + ks) * 1024) = col_ok[t] ? v : make_uint4(0, 0, 0, 0);
+      qf[t][ks] = col_ok[t] ? v : make_uint4(0, 0, 0, 0);
     }
   }
   int kmin = 0x7FFFFFFF;                                         // smallest position among the wave's valid columns
@@ -132,7 +134,6 @@ __global__ __launch_bounds__(kPrefillThreads) void paged_attn_prefill_kernel(
     }
   }
   typedef unsigned int pvec __attribute__((ext_vector_type(4)));
-  // NP = PPT / 2: the K pages only (first pass); NP = PPT: K and V
   auto stage_load = [&](pvec (&regs)[PPT], int tb, auto np) {
     constexpr int NP = decltype(np)::value;
     const int bi = min(tb / BS, last_blk_idx);
@@ -151,7 +152,6 @@ __global__ __launch_bounds__(kPrefillThreads) void paged_attn_prefill_kernel(
 #pragma unroll
     for (int j = 0; j < NP; ++j) *reinterpret_cast<pvec*>(&lds[buf * BUF + dst_off[j]]) = regs[j];
   };
-  const std::integral_constant<int, PPT / 2> k_only;
   const std::integral_constant<int, PPT> k_and_v;
 
   const int steps = (t_end_wg + 31) / 32;
@@ -169,9 +169,8 @@ __global__ __launch_bounds__(kPrefillThreads) void paged_attn_prefill_kernel(
       const uint4 kb = *reinterpret_cast<const uint4*>(base + (KS + ks) * KFRAG);
 #pragma unroll
       for (int t = 0; t < NQ; ++t) {
-        const uint4 qf = *reinterpret_cast<const uint4*>(qlds + (t * KS + ks) * 1024);   // written by this same lane
-        sa[t] = T::mfma(ka, qf, sa[t]);
-        sb[t] = T::mfma(kb, qf, sb[t]);
+        sa[t] = T::mfma(ka, qf[t][ks], sa[t]);
+        sb[t] = T::mfma(kb, qf[t][ks], sb[t]);
       }
     }
     const int tok0 = s * 32 + tok_h;
@@ -187,48 +186,18 @@ __global__ __launch_bounds__(kPrefillThreads) void paged_attn_prefill_kernel(
     }
   };
 
-  // ================= pass 1: the maximum score of every column =================
-  // Two passes instead of an online softmax: with 16 columns per tile a running maximum moves in
-  // most steps, and every move rescales the 128 accumulator registers of O (which the compiler
-  // then also keeps shuttling between register files).  The first pass costs the QK^T MFMAs a
-  // second time (half of all MFMAs) and leaves the second pass a straight line: scores, one fma +
-  // exp2 per score, PV.
-  float mx[NQ];
-#pragma unroll
-  for (int t = 0; t < NQ; ++t) mx[t] = -INFINITY;
-  {
-    pvec r0[PPT];
-    stage_load(r0, 0, k_only);
-    stage_store(r0, 0, k_only);
-  }
-  __syncthreads();
-  for (int s = 0; s < steps; ++s) {
-    const bool more = s + 1 < steps;
-    pvec nxt[PPT];
-    if (more) stage_load(nxt, s * 32 + 32, k_only);             // workgroup-uniform branch
-    f32x4 sa[NQ], sb[NQ];
-    scores(s, sa, sb);
-#pragma unroll
-    for (int t = 0; t < NQ; ++t)
-      mx[t] = fmaxf(mx[t], fmaxf(fmaxf(fmaxf(sa[t][0], sa[t][1]), fmaxf(sa[t][2], sa[t][3])),
-                                 fmaxf(fmaxf(sb[t][0], sb[t][1]), fmaxf(sb[t][2], sb[t][3]))));
-    if (more) stage_store(nxt, (s + 1) & 1, k_only);
-    __syncthreads();                                             // also before the second pass refills buffer 0
-  }
-  float neg_m[NQ], l[NQ];
+  // ================= one pass: scores, probabilities against a lazy reference, O =================
+  float m_ref[NQ], m_thr[NQ], neg_m[NQ], l[NQ];   // in the exponent's units (score * scale * log2 e)
   f32x4 o[NQ][NT];
 #pragma unroll
   for (int t = 0; t < NQ; ++t) {
-    float v = mx[t];
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
-    neg_m[t] = (v == -INFINITY) ? 0.f : -(v * scale_log2e);      // a column that sees no key: exponent reference 0
+    m_ref[t] = m_thr[t] = -INFINITY;
+    neg_m[t] = 0.f;                               // a column that has seen no key yet: exponent reference 0
     l[t] = 0.f;
 #pragma unroll
     for (int n = 0; n < NT; ++n) o[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-
-  // ================= pass 2: probabilities and O =================
+  constexpr float kSlack = 8.f;                   // p <= 2^8 between two updates of the reference
   {
     pvec r0[PPT];
     stage_load(r0, 0, k_and_v);
@@ -238,10 +207,42 @@ __global__ __launch_bounds__(kPrefillThreads) void paged_attn_prefill_kernel(
   for (int s = 0; s < steps; ++s) {
     const bool more = s + 1 < steps;
     pvec nxt[PPT];
-    if (more) stage_load(nxt, s * 32 + 32, k_and_v);
+    if (more) stage_load(nxt, s * 32 + 32, k_and_v);             // workgroup-uniform branch
     f32x4 sa[NQ], sb[NQ];
     scores(s, sa, sb);
-    // p = exp2(s * scale - max) <= 1: the softmax scale is folded into the exponent, one fma per score
+    // does any score of this lane leave the slack above its column's reference?  (scale > 0: the
+    // maximum commutes with the scaling; a masked score is -inf and never does)
+    float lm[NQ];
+    bool grow = false;
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+      lm[t] = scale_log2e * fmaxf(fmaxf(fmaxf(sa[t][0], sa[t][1]), fmaxf(sa[t][2], sa[t][3])),
+                                  fmaxf(fmaxf(sb[t][0], sb[t][1]), fmaxf(sb[t][2], sb[t][3])));
+      grow |= lm[t] > m_thr[t];
+    }
+    if (__any(grow)) {                                           // wave-uniform; rare after a tile's first step
+#pragma unroll
+      for (int t = 0; t < NQ; ++t) {
+        float v = lm[t];
+        v = fmaxf(v, __shfl_xor(v, 16, 64));                     // the column's keys of this step sit on 4 lanes
+        v = fmaxf(v, __shfl_xor(v, 32, 64));
+        const float m_new = fmaxf(m_ref[t], v);
+        // -inf -> finite: alpha = 0 (O and l are still zero); no key seen yet: nothing to rescale
+        const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_ref[t] - m_new);
+        l[t] *= alpha;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          o[t][n][0] *= alpha;
+          o[t][n][1] *= alpha;
+          o[t][n][2] *= alpha;
+          o[t][n][3] *= alpha;
+        }
+        m_ref[t] = m_new;
+        m_thr[t] = m_new + kSlack;                               // -inf stays -inf
+        neg_m[t] = (m_new == -INFINITY) ? 0.f : -m_new;
+      }
+    }
+    // p = exp2(s * scale - m_ref): the softmax scale is folded into the exponent, one fma per score
     uint4 pf[NQ];
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
