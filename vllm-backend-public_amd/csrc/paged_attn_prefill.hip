@@ -35,7 +35,6 @@
 namespace mi355 {
 
 constexpr int kPrefillThreads = 256;
-constexpr int kPrefillWaves = kPrefillThreads / 64;
 
 // Second launch bound: waves per SIMD the register allocation must leave room for.  Two workgroups
 // per CU overlap each other's dependent chains (LDS reads -> MFMAs -> exp2 -> MFMAs -> barrier).
@@ -58,9 +57,24 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
   constexpr int PIECES = 8 * D;                  // 16-byte pieces per step: two K pages + two V pages
   constexpr int PPT = PIECES / kPrefillThreads;  // per thread: 4 (D = 128) or 2 (D = 64)
   static_assert(PIECES % kPrefillThreads == 0, "whole pieces per thread");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+  // HS 32-token images per barrier interval, two intervals in flight: half as many workgroup
+  // barriers per key as with one image, and the second image's QK^T can run under the first one's
+  // exponentials (independent instruction streams inside one basic block)
+  constexpr int HS = 2;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HS * BUF];
 
-  const int qtile = blockIdx.x, kvh = blockIdx.y, seq = blockIdx.z;
+  // Workgroup -> (query tile, kv head, sequence).  The hardware deals consecutive workgroups to the
+  // 8 XCDs in turn, and each XCD has its own L2: with the plain grid order every XCD would walk the
+  // K/V pages of every sequence (16 x 2048 tokens: 16 MB through each 4 MB L2, the launch then runs
+  // at the memory-side cache's rate).  Here XCD x takes a contiguous range of (sequence, kv head)
+  // pairs instead, so the tiles that share pages share an L2; within a pair the LAST query tile
+  // comes first -- it has the most keys to walk (causal), and the short ones fill the tail.
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int total = gx * gy * static_cast<int>(gridDim.z);
+  const int lin = blockIdx.x + gx * (blockIdx.y + gy * static_cast<int>(blockIdx.z));
+  const int xcd = lin & 7;
+  const int work = xcd * (total >> 3) + min(xcd, total & 7) + (lin >> 3);   // bijective on [0, total)
+  const int qtile = gx - 1 - work % gx, kvh = (work / gx) % gy, seq = work / (gx * gy);
   const int group = num_heads / num_kv_heads;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -134,8 +148,8 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
     }
   }
   typedef unsigned int pvec __attribute__((ext_vector_type(4)));
-  auto stage_load = [&](pvec (&regs)[PPT], int tb, auto np) {
-    constexpr int NP = decltype(np)::value;
+  auto stage_load = [&](pvec (&regs)[PPT], int tb) {
+    constexpr int NP = PPT;
     const int bi = min(tb / BS, last_blk_idx);
     int blk[2] = {MI355_LD(int32_t, block_tables, bt + bi), MI355_LD(int32_t, block_tables, bt + min(bi + 1, last_blk_idx))};
     blk[0] = min(max(blk[0], 0), num_blocks - 1);
@@ -147,20 +161,18 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
       regs[j] = MI355_LD(pvec, j < PPT / 2 ? k_cache : v_cache, src);
     }
   };
-  auto stage_store = [&](const pvec (&regs)[PPT], int buf, auto np) {
-    constexpr int NP = decltype(np)::value;
+  auto stage_store = [&](const pvec (&regs)[PPT], int image) {   // image = interval parity * HS + half-step
 #pragma unroll
-    for (int j = 0; j < NP; ++j) *reinterpret_cast<pvec*>(&lds[buf * BUF + dst_off[j]]) = regs[j];
+    for (int j = 0; j < PPT; ++j) *reinterpret_cast<pvec*>(&lds[image * BUF + dst_off[j]]) = regs[j];
   };
-  const std::integral_constant<int, PPT> k_and_v;
 
   const int steps = (t_end_wg + 31) / 32;
   const int tok_h = 8 * h;
 
   // S^T = K . Q^T of one step for all column tiles (a K fragment is read from LDS once and used NQ
   // times), causal mask applied where the step reaches past some column of this wave
-  auto scores = [&](int s, f32x4 (&sa)[NQ], f32x4 (&sb)[NQ]) {
-    const unsigned char* base = &lds[(s & 1) * BUF + lane * 16 + 16 * h];
+  auto scores = [&](int s, int image, f32x4 (&sa)[NQ], f32x4 (&sb)[NQ]) {
+    const unsigned char* base = &lds[image * BUF + lane * 16 + 16 * h];
 #pragma unroll
     for (int t = 0; t < NQ; ++t) sa[t] = sb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -198,18 +210,10 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
     for (int n = 0; n < NT; ++n) o[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   constexpr float kSlack = 8.f;                   // p <= 2^8 between two updates of the reference
-  {
-    pvec r0[PPT];
-    stage_load(r0, 0, k_and_v);
-    stage_store(r0, 0, k_and_v);
-  }
-  __syncthreads();
-  for (int s = 0; s < steps; ++s) {
-    const bool more = s + 1 < steps;
-    pvec nxt[PPT];
-    if (more) stage_load(nxt, s * 32 + 32, k_and_v);             // workgroup-uniform branch
+  // one 32-token image: scores, lazy reference check, probabilities, PV
+  auto half_step = [&](int s, int image) {
     f32x4 sa[NQ], sb[NQ];
-    scores(s, sa, sb);
+    scores(s, image, sa, sb);
     // does any score of this lane leave the slack above its column's reference?  (scale > 0: the
     // maximum commutes with the scaling; a masked score is -inf and never does)
     float lm[NQ];
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
 #pragma unroll
     for (int w = 0; w < 4; ++w)
       msk[w] = ((tok0 + 2 * w < t_end_wg) ? 0x0000FFFFu : 0u) | ((tok0 + 2 * w + 1 < t_end_wg) ? 0xFFFF0000u : 0u);
-    const unsigned char* vbase = &lds[(s & 1) * BUF + KBYTES + lane * 16];
+    const unsigned char* vbase = &lds[image * BUF + KBYTES + lane * 16];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       uint4 vf = *reinterpret_cast<const uint4*>(vbase + n * 1024);
@@ -274,8 +278,31 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
 #pragma unroll
       for (int t = 0; t < NQ; ++t) o[t][n] = T::mfma(vf, pf[t], o[t][n]);
     }
+  };
+
+  {
+#pragma unroll
+    for (int hs = 0; hs < HS; ++hs) {          // images beyond the last step re-read the last pages (clamped), unused
+      pvec r0[PPT];
+      stage_load(r0, hs * 32);
+      stage_store(r0, hs);
+    }
+  }
+  __syncthreads();
+  for (int s = 0; s < steps; s += HS) {
+    const bool more = s + HS < steps;
+    const int par = (s / HS) & 1;
+    pvec nxt[HS][PPT];
+    if (more) {                                                  // workgroup-uniform branch
+#pragma unroll
+      for (int hs = 0; hs < HS; ++hs) stage_load(nxt[hs], (s + HS + hs) * 32);
+    }
+#pragma unroll
+    for (int hs = 0; hs < HS; ++hs)
+      if (s + hs < steps) half_step(s + hs, par * HS + hs);      // workgroup-uniform
     if (more) {
-      stage_store(nxt, (s + 1) & 1, k_and_v);
+#pragma unroll
+      for (int hs = 0; hs < HS; ++hs) stage_store(nxt[hs], (par ^ 1) * HS + hs);
       __syncthreads();
     }
   }
