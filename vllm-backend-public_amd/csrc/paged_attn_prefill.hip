@@ -5,7 +5,7 @@
 // sequence).  A query tile is QT = 64*NQ / group consecutive queries; its (query,
 // head-in-group) pairs -- up to 64*NQ of them -- are laid on MFMA output COLUMNS, 16 per
 // column tile, and wave w owns column tiles w*NQ .. w*NQ+NQ-1 (NQ = 1 or 2 by the chunk
-// length; 4 is built).  The workgroup walks the keys its tile can see in 32-token steps.  The
+// length).  The workgroup walks the keys its tile can see in 32-token steps.  The
 // K and V pages of a step are STAGED THROUGH LDS ONCE PER WORKGROUP, double buffered: all 256
 // threads copy the two pages (coalesced 16-byte pieces, whole 4 KB pages) into an LDS image
 // in FRAGMENT ORDER -- piece (fragment, lane) at (fragment*64 + lane)*16, so every wave's
@@ -36,6 +36,15 @@ namespace mi355 {
 
 constexpr int kPrefillThreads = 256;
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// max of three in one instruction (fmaxf chains go through a canonicalising v_max_f32 per input)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // Second launch bound: waves per SIMD the register allocation must leave room for.  Two workgroups
 // per CU overlap each other's dependent chains (LDS reads -> MFMAs -> exp2 -> MFMAs -> barrier).
 template <typename T, int D, int NQ>
@@ -47,10 +56,13 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
   constexpr int KS = D / 32;
   constexpr int NT = D / 16;
   constexpr int BS = MI355_BLOCK_SIZE;
-  // K image of a step: [tile a/b][k-step][h = lane >> 4][c = lane & 15][16 B], each 16-lane block
-  // followed by 16 B of padding: eight consecutive staging threads write eight (k-step, h) slots
-  // of one row, and 272-byte / 1088-byte strides put those on eight different 16-byte bank groups
-  constexpr int KFRAG = 4 * 272;
+  // K image of a step: [tile a/b][k-step][h = lane >> 4][c' = (lane & 15) ^ (2h + (k-step & 1))][16 B].
+  // Reads (`ds_read_b128`: 16 lanes per LDS cycle, a bank per dword of 256 B) want the lanes of a
+  // 16-lane block on consecutive 16-byte slots; the staging writes (`ds_write_b128`: 8 consecutive
+  // threads per cycle, banks wrapping at 128 B) come as the eight (k-step, h) slots of one key row,
+  // 256 B apart.  The XOR moves those eight onto different bank groups and only permutes the
+  // slots of a block among the lanes that read it: both sides are conflict-free.
+  constexpr int KFRAG = 1024;
   constexpr int KBYTES = 2 * KS * KFRAG;
   constexpr int VBYTES = NT * 1024;              // V image: [16-row tile of head_dim][lane][16 B]
   constexpr int BUF = KBYTES + VBYTES;
@@ -137,7 +149,7 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
       const int cc = (r & 3) | (((r >> 3) & 1) << 2) | (pg << 3);
       src_page[j] = pg;
       src_off[j] = r * D + sl * 8;
-      dst_off[j] = (tile * KS + ks) * KFRAG + hh * 272 + cc * 16;
+      dst_off[j] = (tile * KS + ks) * KFRAG + hh * 256 + (cc ^ (2 * hh + (ks & 1))) * 16;
     } else {                                                     // V: [page][head_dim row][half of the 16 tokens]
       const int g2 = g - PIECES / 2;
       const int pg = g2 / (2 * D), rem = g2 % (2 * D);
@@ -172,13 +184,14 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
   // S^T = K . Q^T of one step for all column tiles (a K fragment is read from LDS once and used NQ
   // times), causal mask applied where the step reaches past some column of this wave
   auto scores = [&](int s, int image, f32x4 (&sa)[NQ], f32x4 (&sb)[NQ]) {
-    const unsigned char* base = &lds[image * BUF + lane * 16 + 16 * h];
+    const unsigned char* base[2] = {&lds[image * BUF + h * 256 + (c ^ (2 * h)) * 16],
+                                    &lds[image * BUF + h * 256 + (c ^ (2 * h + 1)) * 16]};
 #pragma unroll
     for (int t = 0; t < NQ; ++t) sa[t] = sb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const uint4 ka = *reinterpret_cast<const uint4*>(base + ks * KFRAG);
-      const uint4 kb = *reinterpret_cast<const uint4*>(base + (KS + ks) * KFRAG);
+      const uint4 ka = *reinterpret_cast<const uint4*>(base[ks & 1] + ks * KFRAG);
+      const uint4 kb = *reinterpret_cast<const uint4*>(base[ks & 1] + (KS + ks) * KFRAG);
 #pragma unroll
       for (int t = 0; t < NQ; ++t) {
         sa[t] = T::mfma(ka, qf[t][ks], sa[t]);
@@ -199,13 +212,14 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
   };
 
   // ================= one pass: scores, probabilities against a lazy reference, O =================
-  float m_ref[NQ], m_thr[NQ], neg_m[NQ], l[NQ];   // in the exponent's units (score * scale * log2 e)
+  float m_ref[NQ], m_thr[NQ], neg_m[NQ];          // in the exponent's units (score * scale * log2 e)
+  f32x2 l[NQ];                                    // sum of the lane's probabilities, two partial sums
   f32x4 o[NQ][NT];
 #pragma unroll
   for (int t = 0; t < NQ; ++t) {
     m_ref[t] = m_thr[t] = -INFINITY;
     neg_m[t] = 0.f;                               // a column that has seen no key yet: exponent reference 0
-    l[t] = 0.f;
+    l[t] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int n = 0; n < NT; ++n) o[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -220,8 +234,8 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
     bool grow = false;
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
-      lm[t] = scale_log2e * fmaxf(fmaxf(fmaxf(sa[t][0], sa[t][1]), fmaxf(sa[t][2], sa[t][3])),
-                                  fmaxf(fmaxf(sb[t][0], sb[t][1]), fmaxf(sb[t][2], sb[t][3])));
+      lm[t] = scale_log2e * max3(max3(max3(sa[t][0], sa[t][1], sa[t][2]), sa[t][3], sb[t][0]),
+                                 max3(sb[t][1], sb[t][2], sb[t][3]), -INFINITY);
       grow |= lm[t] > m_thr[t];
     }
     if (__any(grow)) {                                           // wave-uniform; rare after a tile's first step
@@ -233,7 +247,7 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
         const float m_new = fmaxf(m_ref[t], v);
         // -inf -> finite: alpha = 0 (O and l are still zero); no key seen yet: nothing to rescale
         const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_ref[t] - m_new);
-        l[t] *= alpha;
+        l[t] *= alpha;                                           // both halves
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           o[t][n][0] *= alpha;
@@ -250,33 +264,46 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
     uint4 pf[NQ];
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
+      const f32x2 sc = {scale_log2e, scale_log2e}, nm = {neg_m[t], neg_m[t]};
+      const f32x2 e[4] = {__builtin_elementwise_fma(f32x2{sa[t][0], sa[t][1]}, sc, nm),   // v_pk_fma_f32
+                          __builtin_elementwise_fma(f32x2{sa[t][2], sa[t][3]}, sc, nm),
+                          __builtin_elementwise_fma(f32x2{sb[t][0], sb[t][1]}, sc, nm),
+                          __builtin_elementwise_fma(f32x2{sb[t][2], sb[t][3]}, sc, nm)};
       float p[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[t][j], scale_log2e, neg_m[t]));
-        p[4 + j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sb[t][j], scale_log2e, neg_m[t]));
+        p[2 * j] = __builtin_amdgcn_exp2f(e[j][0]);
+        p[2 * j + 1] = __builtin_amdgcn_exp2f(e[j][1]);
       }
-      l[t] += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+      l[t] += (f32x2{p[0], p[1]} + f32x2{p[2], p[3]}) + (f32x2{p[4], p[5]} + f32x2{p[6], p[7]});   // v_pk_add_f32
       pf[t] = pack8<T>(p);
     }
     // O^T += V^T . P^T: a V fragment is read once and used NQ times.  In the tile's last step the V
-    // columns of tokens beyond its last query may be unwritten (0 * NaN): cleared by a mask that is
-    // all ones in every other step.
-    const int tok0 = s * 32 + tok_h;
-    uint32_t msk[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w)
-      msk[w] = ((tok0 + 2 * w < t_end_wg) ? 0x0000FFFFu : 0u) | ((tok0 + 2 * w + 1 < t_end_wg) ? 0xFFFF0000u : 0u);
+    // columns of tokens beyond its last query may be unwritten (0 * NaN): cleared by a mask there.
     const unsigned char* vbase = &lds[image * BUF + KBYTES + lane * 16];
+    if (s * 32 + 32 > t_end_wg) {                                // workgroup-uniform: the tile's last step(s)
+      const int tok0 = s * 32 + tok_h;
+      uint32_t msk[4];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      uint4 vf = *reinterpret_cast<const uint4*>(vbase + n * 1024);
-      vf.x &= msk[0];
-      vf.y &= msk[1];
-      vf.z &= msk[2];
-      vf.w &= msk[3];
+      for (int w = 0; w < 4; ++w)
+        msk[w] = ((tok0 + 2 * w < t_end_wg) ? 0x0000FFFFu : 0u) | ((tok0 + 2 * w + 1 < t_end_wg) ? 0xFFFF0000u : 0u);
 #pragma unroll
-      for (int t = 0; t < NQ; ++t) o[t][n] = T::mfma(vf, pf[t], o[t][n]);
+      for (int n = 0; n < NT; ++n) {
+        uint4 vf = *reinterpret_cast<const uint4*>(vbase + n * 1024);
+        vf.x &= msk[0];
+        vf.y &= msk[1];
+        vf.z &= msk[2];
+        vf.w &= msk[3];
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) o[t][n] = T::mfma(vf, pf[t], o[t][n]);
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const uint4 vf = *reinterpret_cast<const uint4*>(vbase + n * 1024);
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) o[t][n] = T::mfma(vf, pf[t], o[t][n]);
+      }
     }
   };
 
@@ -309,7 +336,7 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
 
 #pragma unroll
   for (int t = 0; t < NQ; ++t) {
-    float lt = l[t];
+    float lt = l[t][0] + l[t][1];
     lt += __shfl_xor(lt, 16, 64);
     lt += __shfl_xor(lt, 32, 64);
     if (!col_ok[t]) continue;
@@ -360,16 +387,14 @@ extern "C" int32_t mi355_paged_attn_prefill(void* out, int64_t out_stride, const
                 "%s: dtype %d not supported (bf16/fp16 only)", name, dtype);
   if (num_seqs == 0 || max_q_len == 0) return MI355_OK;
 
-  // column tiles per wave: a workgroup covers 64*nq (query, head) pairs.  Two, not four, beyond
-  // short chunks: the kernel is bound by the latency chain of a step (LDS reads -> MFMAs -> exp ->
-  // MFMAs -> barrier), and at nq = 2 two workgroups share a CU (66 KB of LDS, 168 registers) and
-  // overlap their chains -- measured on 16 x 2048 tokens, 8 heads on one kv head: 422 us against
-  // 569 us at nq = 4 and 471 us at nq = 1.  MI355_PREFILL_NQ=4 selects the wide form for experiments.
+  // column tiles per wave: a workgroup covers 64*nq (query, head) pairs.  Two beyond short chunks:
+  // two workgroups then share a CU (64 KB of LDS and ~250 registers each) and overlap each other's
+  // dependent chains; four tiles per wave (one workgroup per CU) measured slower on every shape.
+  // MI355_PREFILL_NQ=1 selects the narrow form for experiments.
   const int64_t pairs = static_cast<int64_t>(max_q_len) * group;
   int nq = pairs <= 64 ? 1 : 2;
   if (const char* e = getenv("MI355_PREFILL_NQ")) {
-    const int want = atoi(e);
-    if (want == 1 || want == 2 || want == 4) nq = (pairs <= 64 && want > 1) ? nq : want;
+    if (atoi(e) == 1) nq = 1;
   }
   const int qt = 64 * nq / group;                      // queries per workgroup (>= 4: group <= 16)
   dim3 grid((max_q_len + qt - 1) / qt, num_kv_heads, num_seqs), block(kPrefillThreads);
@@ -383,8 +408,7 @@ extern "C" int32_t mi355_paged_attn_prefill(void* out, int64_t out_stride, const
 #define MI355_PRE_NQ(TT, DD)                \
   switch (nq) {                             \
     case 1: MI355_PRE(TT, DD, 1); break;    \
-    case 2: MI355_PRE(TT, DD, 2); break;    \
-    default: MI355_PRE(TT, DD, 4); break;   \
+    default: MI355_PRE(TT, DD, 2); break;   \
   }
   if (dtype == MI355_BF16) {
     if (head_dim == 64) { MI355_PRE_NQ(BF16, 64) } else { MI355_PRE_NQ(BF16, 128) }
