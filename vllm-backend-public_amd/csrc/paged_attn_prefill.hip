@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
   // ---- staging: thread tid copies pieces g = j*256 + tid of a step (j < PPT/2: the two K pages,
   // the rest: the two V pages).  Source addresses walk a page front to back (coalesced);
   // destinations are in fragment order.
-  int src_page[PPT], dst_off[PPT];
+  int src_page[PPT], dst_off[PPT], v_tok[PPT / 2];               // v_tok: token offset of a V piece inside the step
   int64_t src_off[PPT];                                          // element offset inside the (block, kv head) page
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
       const int dr = rem >> 1, half = rem & 1;
       src_page[j] = pg;
       src_off[j] = dr * BS + half * 8;
+      v_tok[j - PPT / 2] = pg * BS + half * 8;
       dst_off[j] = KBYTES + ((dr >> 4) * 64 + (pg * 2 + half) * 16 + (dr & 15)) * 16;
     }
   }
@@ -173,9 +174,26 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
       regs[j] = MI355_LD(pvec, j < PPT / 2 ? k_cache : v_cache, src);
     }
   };
-  auto stage_store = [&](const pvec (&regs)[PPT], int image) {   // image = interval parity * HS + half-step
+  // In the image that reaches the tile's end the V columns of tokens beyond its last query may be
+  // unwritten memory (their probabilities are 0, but 0 * NaN is NaN): cleared here, where no
+  // accumulator is live across the branch, rather than in the MFMA loop.
+  auto stage_store = [&](const pvec (&regs)[PPT], int image, int tb) {   // image = interval parity * HS + half-step
 #pragma unroll
-    for (int j = 0; j < PPT; ++j) *reinterpret_cast<pvec*>(&lds[image * BUF + dst_off[j]]) = regs[j];
+    for (int j = 0; j < PPT / 2; ++j) *reinterpret_cast<pvec*>(&lds[image * BUF + dst_off[j]]) = regs[j];
+    if (tb + 32 > t_end_wg) {                                      // workgroup-uniform
+#pragma unroll
+      for (int j = PPT / 2; j < PPT; ++j) {
+        const int tok = tb + v_tok[j - PPT / 2];                   // first of the piece's 8 tokens
+        pvec v = regs[j];
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+          v[w] &= ((tok + 2 * w < t_end_wg) ? 0x0000FFFFu : 0u) | ((tok + 2 * w + 1 < t_end_wg) ? 0xFFFF0000u : 0u);
+        *reinterpret_cast<pvec*>(&lds[image * BUF + dst_off[j]]) = v;
+      }
+    } else {
+#pragma unroll
+      for (int j = PPT / 2; j < PPT; ++j) *reinterpret_cast<pvec*>(&lds[image * BUF + dst_off[j]]) = regs[j];
+    }
   };
 
   const int steps = (t_end_wg + 31) / 32;
@@ -278,32 +296,14 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
       l[t] += (f32x2{p[0], p[1]} + f32x2{p[2], p[3]}) + (f32x2{p[4], p[5]} + f32x2{p[6], p[7]});   // v_pk_add_f32
       pf[t] = pack8<T>(p);
     }
-    // O^T += V^T . P^T: a V fragment is read once and used NQ times.  In the tile's last step the V
-    // columns of tokens beyond its last query may be unwritten (0 * NaN): cleared by a mask there.
+    // O^T += V^T . P^T: a V fragment is read once and used NQ times (the V columns of tokens beyond
+    // the tile's last query were cleared when the image was staged)
     const unsigned char* vbase = &lds[image * BUF + KBYTES + lane * 16];
-    if (s * 32 + 32 > t_end_wg) {                                // workgroup-uniform: the tile's last step(s)
-      const int tok0 = s * 32 + tok_h;
-      uint32_t msk[4];
 #pragma unroll
-      for (int w = 0; w < 4; ++w)
-        msk[w] = ((tok0 + 2 * w < t_end_wg) ? 0x0000FFFFu : 0u) | ((tok0 + 2 * w + 1 < t_end_wg) ? 0xFFFF0000u : 0u);
+    for (int n = 0; n < NT; ++n) {
+      const uint4 vf = *reinterpret_cast<const uint4*>(vbase + n * 1024);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        uint4 vf = *reinterpret_cast<const uint4*>(vbase + n * 1024);
-        vf.x &= msk[0];
-        vf.y &= msk[1];
-        vf.z &= msk[2];
-        vf.w &= msk[3];
-#pragma unroll
-        for (int t = 0; t < NQ; ++t) o[t][n] = T::mfma(vf, pf[t], o[t][n]);
-      }
-    } else {
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const uint4 vf = *reinterpret_cast<const uint4*>(vbase + n * 1024);
-#pragma unroll
-        for (int t = 0; t < NQ; ++t) o[t][n] = T::mfma(vf, pf[t], o[t][n]);
-      }
+      for (int t = 0; t < NQ; ++t) o[t][n] = T::mfma(vf, pf[t], o[t][n]);
     }
   };
 
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
     for (int hs = 0; hs < HS; ++hs) {          // images beyond the last step re-read the last pages (clamped), unused
       pvec r0[PPT];
       stage_load(r0, hs * 32);
-      stage_store(r0, hs);
+      stage_store(r0, hs, hs * 32);
     }
   }
   __syncthreads();
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
       if (s + hs < steps) half_step(s + hs, par * HS + hs);      // workgroup-uniform
     if (more) {
 #pragma unroll
-      for (int hs = 0; hs < HS; ++hs) stage_store(nxt[hs], (par ^ 1) * HS + hs);
+      for (int hs = 0; hs < HS; ++hs) stage_store(nxt[hs], (par ^ 1) * HS + hs, (s + HS + hs) * 32);
       __syncthreads();
     }
   }
