@@ -156,9 +156,15 @@ def time_kernels(engine, batch, ctx_len):
     else:
         out["gemm_gate_up"] = timed(lambda i: torch.mm(x, W[i].gate_up_w.t(), out=gu), gemm(b, 2 * r.F, r.H, w_es=es))
         out["silu_and_mul"] = timed(lambda i: ops.silu_and_mul(gu, out=act), 3 * b * r.F * es)
-    if mode["down"]:
+    # a projection whose output is all-reduced (o under tensor parallelism, down when the MLP is
+    # sharded) stores 16 bits instead of fp32 slabs: time the form the step runs
+    slabs_o = mode["o"] and r.tiled_shapes["o"][2]
+    slabs_dn = mode["down"] and r.tiled_shapes["down"][2]
+    if slabs_dn:
         out["gemm_down"] = timed(lambda i: lt(act, T[i]["down"], r.H, partial=r.part_dn, tiles_per_wg=td,
                                               k_groups=gd, epilogue=P), gemm(b, r.H, r.F, 4 * gd))
+    elif mode["down"]:
+        out["gemm_down"] = timed(lambda i: lt(act, T[i]["down"], r.H, out=dn, tiles_per_wg=td), gemm(b, r.H, r.F))
     else:
         out["gemm_down"] = timed(lambda i: torch.mm(act, W[i].down_w.t(), out=dn), gemm(b, r.H, r.F, w_es=es))
     if mode["qkv"]:
@@ -166,9 +172,11 @@ def time_kernels(engine, batch, ctx_len):
                                              k_groups=gq, epilogue=P), gemm(b, r.qw, r.H, 4 * gq))
     else:
         out["gemm_qkv"] = timed(lambda i: torch.mm(x, W[i].qkv_w.t(), out=qkv), gemm(b, r.qw, r.H, w_es=es))
-    if mode["o"]:
+    if slabs_o:
         out["gemm_o"] = timed(lambda i: lt(attn, T[i]["o"], r.H, partial=r.part_o, tiles_per_wg=to,
                                            k_groups=go, epilogue=P), gemm(b, r.H, r.nh * r.d, 4 * go))
+    elif mode["o"]:
+        out["gemm_o"] = timed(lambda i: lt(attn, T[i]["o"], r.H, out=o, tiles_per_wg=to), gemm(b, r.H, r.nh * r.d))
     else:
         out["gemm_o"] = timed(lambda i: torch.mm(attn, W[i].o_w.t(), out=o), gemm(b, r.H, r.nh * r.d, w_es=es))
     lm = r.w.lm_head
@@ -179,7 +187,7 @@ def time_kernels(engine, batch, ctx_len):
     ctx_tokens = int(r.ctx[:b].sum().item())              # the device buffers still hold the last step's inputs
     kv_bytes = ctx_tokens * 2 * r.nkv * r.d * es + 2 * b * r.nh * r.d * es
     rope_bytes = b * ((r.nh + r.nkv) * r.d * 2 + r.nkv * r.d + 2 * r.nkv * r.d) * es
-    if mode["down"]:
+    if slabs_dn:
         out["fused_add_rms_norm"] = timed(
             lambda i: ops.fused_add_rms_norm_partial(r.part_dn, gd, resid, W[i].post_norm, r.eps, x),
             b * r.H * (4 * gd + 3 * es))
@@ -630,7 +638,8 @@ def main():
     result["degraded"] = {"hip_graphs": bool(r_.use_graphs), "graph_capture_failures": r_.capture_failures,
                           "gemm_tune_failures": r_.tune_failures,
                           "allreduce": ("none (1 GPU)" if tp == 1 else
-                                        "one-shot kernel over IPC-mapped buffers" if r_.oneshot is not None else "RCCL"),
+                                        "one-shot kernel over IPC-mapped buffers" if r_.oneshot is not None else
+                                        ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal)")),
                           "gemm_form": {k: ("tiled" if v else "library") for k, v in r_._mode(batch).items()}}
 
     kern = None
