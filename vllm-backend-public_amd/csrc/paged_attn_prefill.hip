@@ -206,6 +206,7 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
                                     &lds[image * BUF + h * 256 + (c ^ (2 * h + 1)) * 16]};
 #pragma unroll
     for (int t = 0; t < NQ; ++t) sa[t] = sb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const uint4 ka = *reinterpret_cast<const uint4*>(base[ks & 1] + ks * KFRAG);
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
         sb[t] = T::mfma(kb, qf[t][ks], sb[t]);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     const int tok0 = s * 32 + tok_h;
     if (s * 32 + 32 > t_min + 1) {         // wave-uniform: on or beyond the diagonal for some column
 #pragma unroll
@@ -299,12 +301,14 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
     // O^T += V^T . P^T: a V fragment is read once and used NQ times (the V columns of tokens beyond
     // the tile's last query were cleared when the image was staged)
     const unsigned char* vbase = &lds[image * BUF + KBYTES + lane * 16];
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       const uint4 vf = *reinterpret_cast<const uint4*>(vbase + n * 1024);
 #pragma unroll
       for (int t = 0; t < NQ; ++t) o[t][n] = T::mfma(vf, pf[t], o[t][n]);
     }
+    __builtin_amdgcn_s_setprio(0);
   };
 
   {
