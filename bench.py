@@ -154,7 +154,7 @@ def time_kernels(engine, batch, ctx_len):
                                                  epilogue=ops.EPI_SILU_MUL),
                                     2 * r.F * r.H * wes + b * r.H * es + b * r.F * es)
     else:
-        out["gemm_gate_up"] = timed(lambda i: torch.mm(x, W[i].gate_up_w.t(), out=gu), gemm(b, 2 * r.F, r.H, w_es=es))
+        out["gemm_gate_up"] = timed(lambda i: torch.mm(x, r._rm(i, "gu").t(), out=gu), gemm(b, 2 * r.F, r.H, w_es=es))
         out["silu_and_mul"] = timed(lambda i: ops.silu_and_mul(gu, out=act), 3 * b * r.F * es)
     # a projection whose output is all-reduced (o under tensor parallelism, down when the MLP is
     # sharded) stores 16 bits instead of fp32 slabs: time the form the step runs
@@ -166,19 +166,19 @@ def time_kernels(engine, batch, ctx_len):
     elif mode["down"]:
         out["gemm_down"] = timed(lambda i: lt(act, T[i]["down"], r.H, out=dn, tiles_per_wg=td), gemm(b, r.H, r.F))
     else:
-        out["gemm_down"] = timed(lambda i: torch.mm(act, W[i].down_w.t(), out=dn), gemm(b, r.H, r.F, w_es=es))
+        out["gemm_down"] = timed(lambda i: torch.mm(act, r._rm(i, "down").t(), out=dn), gemm(b, r.H, r.F, w_es=es))
     if mode["qkv"]:
         out["gemm_qkv"] = timed(lambda i: lt(x, T[i]["qkv"], r.qw, partial=r.part_qkv, tiles_per_wg=tq,
                                              k_groups=gq, epilogue=P), gemm(b, r.qw, r.H, 4 * gq))
     else:
-        out["gemm_qkv"] = timed(lambda i: torch.mm(x, W[i].qkv_w.t(), out=qkv), gemm(b, r.qw, r.H, w_es=es))
+        out["gemm_qkv"] = timed(lambda i: torch.mm(x, r._rm(i, "qkv").t(), out=qkv), gemm(b, r.qw, r.H, w_es=es))
     if slabs_o:
         out["gemm_o"] = timed(lambda i: lt(attn, T[i]["o"], r.H, partial=r.part_o, tiles_per_wg=to,
                                            k_groups=go, epilogue=P), gemm(b, r.H, r.nh * r.d, 4 * go))
     elif mode["o"]:
         out["gemm_o"] = timed(lambda i: lt(attn, T[i]["o"], r.H, out=o, tiles_per_wg=to), gemm(b, r.H, r.nh * r.d))
     else:
-        out["gemm_o"] = timed(lambda i: torch.mm(attn, W[i].o_w.t(), out=o), gemm(b, r.H, r.nh * r.d, w_es=es))
+        out["gemm_o"] = timed(lambda i: torch.mm(attn, r._rm(i, "o").t(), out=o), gemm(b, r.H, r.nh * r.d, w_es=es))
     lm = r.w.lm_head
     out["gemm_lm_head"] = timed(lambda i: r.lm_head_logits(x, r.logits[:b]), gemm(b, r.Vl, r.H, w_es=es))
 
@@ -611,7 +611,10 @@ def main():
                                    + ("sharded over the vocabulary, greedy keys max-reduced)" if vocab_tp > 1 else "replicated)")
                                    if mlp_tp > 1 else
                                    f"tp{tp} (attention heads sharded, MLP+lm_head replicated)") if tp > 1 else "tp1",
-                   "mean_context": round(mean_ctx, 1), "hip_graphs": bool(engine.runner.use_graphs)},
+                   "mean_context": round(mean_ctx, 1), "hip_graphs": bool(engine.runner.use_graphs),
+                   "weight_copies": ("tiled only (MI355_SINGLE_WEIGHT_COPY=1)"
+                                     if getattr(engine.runner, "single_weight_copy", False) else "row-major + tiled"),
+                   "gpu_memory_allocated_gb": round(torch.cuda.memory_allocated() / 1e9, 2)},
         "segments": {"count": len(regions), "reported": "median", "steps_each": a.steps,
                      "ms_per_step_each": [round(t / a.steps * 1e3, 4) for t, _ in regions]},
         "ttft_ms_p50": round(ttft_ms, 2),

@@ -415,6 +415,21 @@ int32_t mi355_tile_weights(void* dst, const void* src, int32_t N, int32_t K,
                            int32_t interleave_halves, void* stream);
 
 /*
+ * The inverse re-layouts: fragment-tiled weights back to a row-major [N, K]
+ * matrix in the model's 16-bit type (rows the tiling padded are dropped).  The
+ * fp8 form decodes, dst = round(fp8 * row scale): the matrix the tiled GEMM
+ * multiplies by.  An engine that keeps ONLY the tiled copy of its decode weights
+ * (half the weight memory) rebuilds a row-major matrix into a scratch buffer
+ * when a library GEMM (prefill, batches beyond 128 rows) needs one.  No
+ * counterpart in the reference: memory layout of this engine only.
+ */
+int32_t mi355_untile_weights(void* dst, const void* src_tiled, int32_t N, int32_t K,
+                             int32_t interleave_halves, void* stream);
+int32_t mi355_untile_weights_fp8(void* dst, const void* src_tiled, const float* scale_tiled,
+                                 int32_t N, int32_t K, int32_t interleave_halves,
+                                 int32_t dtype, void* stream);
+
+/*
  * Decode-time linear layer on fragment-tiled weights, M <= 128:
  * y[M, N] = x[M, K] . W[N, K]^T.  Every weight load is 1 KB of contiguous memory
  * and each wave streams one 16-row tile of W; x is staged through LDS once per

@@ -377,6 +377,44 @@ def test_fp8_weights_engine_matches_oracle_on_the_quantised_model(name, monkeypa
     assert np.abs(full_logits[0] - ref_logits[0]).max() > 4 * 2.0 ** -8 * scale
 
 
+@pytest.mark.parametrize("name,quant", [("llama_d128", None), ("qwen2_d128", None), ("llama_d128", "fp8")])
+def test_single_weight_copy_serves_the_same_tokens(name, quant, monkeypatch):
+    """MI355_SINGLE_WEIGHT_COPY=1: the row-major weights are freed once tiled, and prefill (and a
+    decode step on library GEMMs) rebuilds them from the tiled (or fp8) copy -- the same bits, so
+    the same logits and tokens as the engine that keeps both copies."""
+    prompts = make_prompts(name, len(LENGTHS), LENGTHS)
+    kw = {"quantization": quant} if quant else {}
+
+    def run(eng):
+        toks = engine_generate(eng, prompts, 12)
+        return toks, eng.runner.logits[: len(prompts)].float().cpu().numpy().copy()
+
+    def both_forms(eng):
+        """(tokens, logits) with the tiled decode GEMMs, then with every projection sent to the library."""
+        r = eng.runner
+        tiled = run(eng)
+        r._modes = {b: {k: False for k in r.KINDS} for b in r.buckets}
+        r.graphs.clear()
+        return tiled, run(eng)
+
+    monkeypatch.setenv("MI355_TILED_LINEARS", "1")
+    monkeypatch.delenv("MI355_SINGLE_WEIGHT_COPY", raising=False)
+    eng, _, _ = build(name, "bfloat16", **kw)
+    assert eng.runner.w.layers[0].qkv_w is not None
+    want = both_forms(eng)
+    del eng
+    torch.cuda.empty_cache()
+    monkeypatch.setenv("MI355_SINGLE_WEIGHT_COPY", "1")
+    eng, _, _ = build(name, "bfloat16", **kw)
+    r = eng.runner
+    assert r.single_weight_copy and all(getattr(lw, a) is None for lw in r.w.layers
+                                        for a in ("qkv_w", "o_w", "gate_up_w", "down_w")), "row-major copies kept"
+    got = both_forms(eng)                      # library form: every step rebuilds the matrices it multiplies by
+    for (t_got, l_got), (t_want, l_want) in zip(got, want):
+        np.testing.assert_array_equal(t_got, t_want)
+        np.testing.assert_array_equal(l_got, l_want)
+
+
 def test_logprobs_through_the_engine_match_the_oracle():
     """`logprobs=k`: the engine's per-token log-probabilities and top-k lists against the log-softmax
     of the oracle's logits for the same tokens (prefill token and decode tokens, run-ahead on)."""

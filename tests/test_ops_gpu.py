@@ -1118,6 +1118,39 @@ def test_tile_weights_fp8(ops, dtype, N, K, inter):
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("N,K,inter", [(64, 512, False), (1000, 1024, False), (4096, 4096, False), (1536, 1024, True),
+                                       (40, 128, False)])
+def test_untile_weights_is_the_inverse_of_tile_weights(ops, dtype, N, K, inter):
+    """Tiled -> row-major gives back the same bits (rows the tiling padded are dropped), and a
+    destination larger than the matrix is not written beyond it."""
+    rng = rng_for("untile", dtype, N, K)
+    w = grid(rng, (N, K), dtype, 0.05)
+    wd = dev(w, dtype)
+    t = ops.tile_weights(wd, interleave_halves=inter)
+    guard = torch.full((N + 3, K), 7.0, dtype=wd.dtype, device="cuda")
+    back = ops.untile_weights(t, N, K, wd.dtype, interleave_halves=inter, out=guard[:N])
+    assert torch.equal(back.view(torch.int16), wd.view(torch.int16))
+    assert (guard[N:] == 7.0).all()
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("N,K,inter", [(64, 512, False), (1000, 1024, False), (1536, 1024, True), (4096, 4096, False)])
+def test_untile_weights_fp8_decodes_to_the_quantised_matrix(ops, dtype, N, K, inter):
+    """fp8 tiles -> row-major 16-bit: round(fp8 * row scale) bit for bit, i.e. the oracle's quantised
+    model, which is also what the engine's row-major copies hold under --quantization fp8."""
+    rng = rng_for("untile-fp8", dtype, N, K)
+    w = grid(rng, (N, K), dtype, 0.05)
+    w[3] = 0.0
+    w[5, 7] = R.round_to(np.float32(3.0), dtype)
+    wd = dev(w, dtype)
+    qs = ops.tile_weights_fp8(wd, interleave_halves=inter)
+    back = host(ops.untile_weights(qs, N, K, wd.dtype, interleave_halves=inter))
+    q_ref, s_ref = R.quantize_rows_fp8(w)
+    want = R.round_to((q_ref * s_ref[:, None]).astype(np.float32), dtype)
+    np.testing.assert_array_equal(back, want)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 @pytest.mark.parametrize("M,N,K,tiles,groups,bias", [(32, 4096, 4096, 104, 4, False), (32, 28672, 4096, 8, 1, False),
                                                      (7, 1000, 1024, 104, 1, True), (64, 3584, 18944, 104, 4, False),
                                                      (128, 4608, 3584, 8, 7, True), (1, 64, 512, 104, 1, False),

@@ -916,6 +916,53 @@ __global__ __launch_bounds__(64) void tile_weights_fp8_kernel(unsigned char* __r
   }
 }
 
+// ---- the inverse re-layouts: tiled blocks back to a row-major [N, K] matrix in the model's 16-bit
+// type (the fp8 form decodes: round(fp8 * row scale), the matrix the tiled GEMM multiplies by up to
+// its accumulation order).  An engine that keeps only the tiled copy of a weight rebuilds the
+// row-major one into a scratch buffer when a library GEMM needs it.
+template <int DUMMY>
+__global__ __launch_bounds__(64) void untile_weights_kernel(uint16_t* __restrict__ dst, const uint16_t* __restrict__ src,
+                                                            int N, int K, int tiles_total, int interleave_halves) {
+  const int64_t blocks = static_cast<int64_t>(tiles_total) * (K >> 5);
+  const int lane = threadIdx.x, i = lane & 15, h = lane >> 4;
+  for (int64_t b = blockIdx.x; b < blocks; b += gridDim.x) {   // b: source block, [k group][tile][k-step in group]
+    const int ks = static_cast<int>(b / (static_cast<int64_t>(tiles_total) * kTU)) * kTU + static_cast<int>(b % kTU);
+    const int tile = static_cast<int>(b / kTU % tiles_total);
+    const int row = tiled_source_row(tile, i, N, interleave_halves);
+    if (row < 0) continue;
+    const uint4 v = MI355_LD(uint4, src, src + (b * 64 + lane) * 8);
+    MI355_ST(uint4, dst, dst + static_cast<int64_t>(row) * K + 32 * ks + 8 * h, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void untile_weights_fp8_kernel(uint16_t* __restrict__ dst, const unsigned char* __restrict__ src,
+                                                                const float* __restrict__ scale_t, int N, int K,
+                                                                int tiles_total, int interleave_halves) {
+  const int64_t blocks = static_cast<int64_t>(tiles_total) * (K >> 6);
+  const int lane = threadIdx.x, i = lane & 15, h = lane >> 4;
+  constexpr int BPG = kTU / 2;
+  for (int64_t b = blockIdx.x; b < blocks; b += gridDim.x) {   // b: source block, [k group][tile][pair in group]
+    const int kp = static_cast<int>(b / (static_cast<int64_t>(tiles_total) * BPG)) * BPG + static_cast<int>(b % BPG);
+    const int tile = static_cast<int>(b / BPG % tiles_total);
+    const int row = tiled_source_row(tile, i, N, interleave_halves);
+    if (row < 0) continue;
+    const float sc = MI355_LD(float, scale_t, scale_t + (tile * 16 + i));
+    const uint4 w = MI355_LD(uint4, src, src + (b * 64 + lane) * 16);
+    const uint32_t q[4] = {w.x, w.y, w.z, w.w};
+    uint16_t* p = dst + static_cast<int64_t>(row) * K + 64 * kp + 8 * h;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const uint32_t lo = q[2 * half], hi = q[2 * half + 1];
+      float f[8];
+      unpack8<T>(make_uint4(T::fp8x2(lo, false), T::fp8x2(lo, true), T::fp8x2(hi, false), T::fp8x2(hi, true)), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] *= sc;
+      MI355_ST(uint4, dst, p + 32 * half, pack8<T>(f));
+    }
+  }
+}
+
 #define MI355_LT_ARGS y, partial, x, wt, bias, M, N, K, xs, ys, tiles_total, phases
 #define MI355_LT_PARAMS                                                                                       \
   uint16_t *y, float *partial, const uint16_t *x, const uint16_t *wt, const uint16_t *bias, int M, int N, int K, \
@@ -1170,6 +1217,48 @@ extern "C" int32_t mi355_tile_weights(void* dst, const void* src, int32_t N, int
   hipLaunchKernelGGL((tile_weights_kernel<0>), dim3(static_cast<unsigned>(blocks > 65535 ? 65535 : blocks)), dim3(64), 0,
                      static_cast<hipStream_t>(stream), static_cast<uint16_t*>(dst), static_cast<const uint16_t*>(src), N,
                      K, tiles, interleave_halves);
+  return check_launch(name);
+}
+
+extern "C" int32_t mi355_untile_weights(void* dst, const void* src_tiled, int32_t N, int32_t K,
+                                        int32_t interleave_halves, void* stream) {
+  using namespace mi355;
+  const char* name = "mi355_untile_weights";
+  MI355_REQUIRE(dst && src_tiled && dst != src_tiled, MI355_ERR_INVALID, "%s: null or aliased pointers", name);
+  MI355_REQUIRE(N > 0 && K > 0 && K % 128 == 0, MI355_ERR_UNSUPPORTED, "%s: K %d must be a multiple of 128", name, K);
+  MI355_REQUIRE(!interleave_halves || N % 32 == 0, MI355_ERR_UNSUPPORTED,
+                "%s: interleaving needs N %% 32 == 0 (two halves of whole 16-row tiles)", name);
+  MI355_REQUIRE(aligned16(dst) && aligned16(src_tiled), MI355_ERR_INVALID, "%s: pointers must be 16-byte aligned", name);
+  const int tiles = (N + 15) / 16;
+  const int64_t blocks = static_cast<int64_t>(tiles) * (K / 32);
+  hipLaunchKernelGGL((untile_weights_kernel<0>), dim3(static_cast<unsigned>(blocks > 65535 ? 65535 : blocks)), dim3(64), 0,
+                     static_cast<hipStream_t>(stream), static_cast<uint16_t*>(dst),
+                     static_cast<const uint16_t*>(src_tiled), N, K, tiles, interleave_halves);
+  return check_launch(name);
+}
+
+extern "C" int32_t mi355_untile_weights_fp8(void* dst, const void* src_tiled, const float* scale_tiled, int32_t N,
+                                            int32_t K, int32_t interleave_halves, int32_t dtype, void* stream) {
+  using namespace mi355;
+  const char* name = "mi355_untile_weights_fp8";
+  MI355_REQUIRE(dst && src_tiled && scale_tiled && dst != src_tiled, MI355_ERR_INVALID, "%s: null or aliased pointers", name);
+  MI355_REQUIRE(N > 0 && K > 0 && K % 128 == 0, MI355_ERR_UNSUPPORTED, "%s: K %d must be a multiple of 128", name, K);
+  MI355_REQUIRE(!interleave_halves || N % 32 == 0, MI355_ERR_UNSUPPORTED,
+                "%s: interleaving needs N %% 32 == 0 (two halves of whole 16-row tiles)", name);
+  MI355_REQUIRE(aligned16(dst) && aligned16(src_tiled) && aligned16(scale_tiled), MI355_ERR_INVALID,
+                "%s: pointers must be 16-byte aligned", name);
+  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED,
+                "%s: dtype %d not supported (bf16/fp16 only)", name, dtype);
+  const int tiles = (N + 15) / 16;
+  const int64_t blocks = static_cast<int64_t>(tiles) * (K / 64);
+  const dim3 grid(static_cast<unsigned>(blocks > 65535 ? 65535 : blocks)), block(64);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == MI355_BF16)
+    hipLaunchKernelGGL((untile_weights_fp8_kernel<BF16>), grid, block, 0, s, static_cast<uint16_t*>(dst),
+                       static_cast<const unsigned char*>(src_tiled), scale_tiled, N, K, tiles, interleave_halves);
+  else
+    hipLaunchKernelGGL((untile_weights_fp8_kernel<F16>), grid, block, 0, s, static_cast<uint16_t*>(dst),
+                       static_cast<const unsigned char*>(src_tiled), scale_tiled, N, K, tiles, interleave_halves);
   return check_launch(name);
 }
 

@@ -63,6 +63,8 @@ def _load() -> ctypes.CDLL:
         "mi355_argmax_key_to_index": (I32, [P, P, I32, P]),
         "mi355_tiled_weight_elems": (I64, [I32, I32]),
         "mi355_tile_weights": (I32, [P, P, I32, I32, I32, P]),
+        "mi355_untile_weights": (I32, [P, P, I32, I32, I32, P]),
+        "mi355_untile_weights_fp8": (I32, [P, P, P, I32, I32, I32, I32, P]),
         "mi355_linear_tiled": (I32, [P, I64, P, P, I64, P, P, I32, I32, I32, I32, I32, I32, I32, P]),
         "mi355_token_logprobs": (I32, [P, P, P, I64, I32, I32, I32, P, P]),
         "mi355_tiled_weight_fp8_bytes": (I64, [I32, I32]),
@@ -104,7 +106,8 @@ EXPORTS = ("mi355_abi_version", "mi355_last_error", "mi355_target_arch",
            "mi355_layer_norm", "mi355_fused_add_layer_norm", "mi355_embed_pos_layer_norm", "mi355_relu",
            "mi355_argmax_shard_key", "mi355_argmax_key_to_index",
            "mi355_linear_decode", "mi355_sample_topk_topp",
-           "mi355_tiled_weight_elems", "mi355_tile_weights", "mi355_linear_tiled",
+           "mi355_tiled_weight_elems", "mi355_tile_weights", "mi355_untile_weights", "mi355_untile_weights_fp8",
+           "mi355_linear_tiled",
            "mi355_fused_add_rms_norm_partial", "mi355_rope_kv_write_partial",
            "mi355_linear_tiled_fused", "mi355_paged_attn_decode_fused",
            "mi355_tiled_weight_fp8_bytes", "mi355_tile_weights_fp8", "mi355_linear_tiled_w8",

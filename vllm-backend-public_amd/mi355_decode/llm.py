@@ -115,6 +115,14 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
         tiled_bytes = sum(t.numel() * (1 if fp8 else t.element_size()) for lw in weights.layers
                           for t in (lw.qkv_w, lw.gate_up_w, lw.o_w, lw.down_w))
         tiled_bytes += weights.lm_head.numel() * weights.lm_head.element_size()
+    # MI355_SINGLE_WEIGHT_COPY=1: the tiled copy replaces the row-major one (half the weight memory:
+    # what lets a model whose weights fill more than half the card be served at all); prefill then
+    # rebuilds each layer's row-major matrices into scratch buffers, ~10 % more time to first token
+    single = os.environ.get("MI355_SINGLE_WEIGHT_COPY", "0") == "1" and cfg.family != "opt"
+    if single and weights.layers:
+        lw0 = weights.layers[0]
+        scratch = sum(t.numel() * t.element_size() for t in (lw0.qkv_w, lw0.gate_up_w, lw0.o_w, lw0.down_w))
+        tiled_bytes = scratch + weights.lm_head.numel() * weights.lm_head.element_size()
     num_blocks = plan_num_blocks(args, cfg, tp, len(weights.layers), max_model_len,
                                  torch.empty(0, dtype=dtype).element_size(), device, extra_reserve=tiled_bytes)
     # only RCCL collectives can be captured into the decode graph
@@ -123,9 +131,10 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
     if cfg.family == "opt":
         from .opt_runner import OPTRunner
         runner_cls = OPTRunner
+    extra = {"single_weight_copy": True} if single else {}
     runner = runner_cls(cfg, weights, dtype, device, num_blocks, args.max_num_seqs, max_model_len,
                          tp_rank=rank, tp_size=tp, tp_group=group, use_graphs=graphs,
-                         decode_splits=decode_splits, weight_fp8=(args.quantization or "").lower() == "fp8")
+                         decode_splits=decode_splits, weight_fp8=(args.quantization or "").lower() == "fp8", **extra)
     if tp > 1 and os.environ.get("MI355_ONESHOT_ALLREDUCE", "0") == "1":
         # opt-in: the hand-written one-shot all-reduce for decode-sized messages (run with two ranks on
         # one GPU so far, not across xGMI links); larger messages stay on the process group
@@ -135,9 +144,10 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
         log.info("rank %d: one-shot all-reduce for messages up to %d bytes", rank, runner.oneshot.max_bytes)
     if os.environ.get("MI355_LAZY_TUNE", "0") != "1":
         runner.warm_up()                              # every rank, same order: the choices are broadcast
-    log.info("tensor-parallel rank %d of %d on %s: %d layers, MLP %s, lm_head %s, %d KV pages, HIP graphs %s",
+    log.info("tensor-parallel rank %d of %d on %s: %d layers, MLP %s, lm_head %s, %d KV pages, HIP graphs %s, %s",
              rank, tp, device, len(weights.layers), "sharded" if shard_mlp else "whole",
-             "sharded" if shard_vocab else "whole", num_blocks, "on" if graphs else "off")
+             "sharded" if shard_vocab else "whole", num_blocks, "on" if graphs else "off",
+             "tiled weight copy only" if single else "row-major + tiled weight copies")
     eos = cfg.eos_token_id
     eos = [] if eos is None else (list(eos) if isinstance(eos, (list, tuple)) else [eos])
     return LLMEngine(runner, args.max_num_seqs, max(args.max_num_batched_tokens, 1), max_model_len, eos,

@@ -67,7 +67,7 @@ class ModelRunner:
                  num_blocks: int, max_num_seqs: int, max_model_len: int, tp_rank: int = 0,
                  tp_size: int = 1, tp_group=None, use_graphs: bool = True,
                  decode_splits: Optional[int] = None, tiled_linears: Optional[bool] = None,
-                 weight_fp8: bool = False):
+                 weight_fp8: bool = False, single_weight_copy: bool = False):
         self.cfg, self.w, self.dtype, self.device = cfg, weights, dtype, torch.device(device)
         self.tp_rank, self.tp_size, self.tp_group = tp_rank, tp_size, tp_group
         self.nh = cfg.num_attention_heads // tp_size
@@ -108,6 +108,9 @@ class ModelRunner:
         self.oneshot_calls = 0
         self.decode_splits = decode_splits
         self.weight_fp8 = bool(weight_fp8)
+        # keep only the fragment-tiled copy of every decode weight (see _init_tiled / _rm)
+        self.single_weight_copy = bool(single_weight_copy)
+        self._rm_scratch = {}
 
         dev = self.device
         self.cos_sin = build_cos_sin_table(cfg, self.max_model_len, dtype, dev)
@@ -192,6 +195,9 @@ class ModelRunner:
         if want is None and os.environ.get("MI355_TILED_LINEARS") in ("0", "1"):
             self.tiled_policy = "on" if os.environ["MI355_TILED_LINEARS"] == "1" else "off"
         self.tiled = None
+        self._rm_attr = {"qkv": "qkv_w", "o": "o_w", "gu": "gate_up_w", "down": "down_w"}
+        self._rm_shape = {"qkv": (self.qw, self.H), "o": (self.H, self.nh * self.d), "gu": (2 * self.F, self.H),
+                          "down": (self.H, self.F)}
         self._modes = {}
         self._plan_cache = {}
         self._tuned_plans = {}                        # bucket -> {projection: (tiles_per_wg, k_groups)} picked by tune()
@@ -220,6 +226,18 @@ class ModelRunner:
         for lw in self.w.layers:
             self.tiled.append({k: tile(getattr(lw, src[k]), interleave_halves=(k == "gu"))
                                for k in src if k in self.tiled_shapes})
+            if self.single_weight_copy:
+                # The tiled copy becomes the only one: the row-major matrix a library GEMM needs
+                # (prefill, batches beyond 128 rows) is rebuilt from it into a scratch buffer on
+                # demand (_rm).  Freed layer by layer, so the two copies never coexist for more
+                # than one layer.
+                for k in src:
+                    if k in self.tiled_shapes:
+                        setattr(lw, src[k], None)
+        if self.single_weight_copy:                       # one scratch matrix per projection, before any graph capture
+            for k in src:
+                if k in self.tiled_shapes:
+                    self._rm_scratch[k] = torch.empty(*self._rm_shape[k], dtype=self.dtype, device=self.device)
         self.lm_head_tiled = ops.tile_weights(self.w.lm_head) if "lm_head" in self.tiled_shapes else None
         f32 = dict(dtype=torch.float32, device=self.device)
         size = {k: 0 for k in ("qkv", "o", "down")}
@@ -232,23 +250,46 @@ class ModelRunner:
         self.part_dn = torch.empty(max(size["down"], 4), **f32)
 
     def _fake_quantize_row_major(self) -> None:
-        """--quantization fp8: the row-major matrices (prefill, large batches, the TP o projection) are
-        replaced by what the fp8 copies decode to -- round(fp8(w / scale) * scale), scale = max|row| / 448
-        -- so that every path computes with the same quantised model."""
+        """--quantization fp8: the row-major matrices (prefill, large batches) are replaced by what
+        the fp8 copies decode to -- round(fp8(w / scale) * scale), scale = max|row| / 448 -- so that
+        every path computes with the same quantised model.  A projection that has an fp8 tiled copy
+        is decoded from it (the same bits the decode GEMM multiplies by); one without is quantised
+        with the library's conversion."""
         def fq(w: torch.Tensor) -> None:
             f = w.float()
             amax = f.abs().amax(dim=1, keepdim=True)
             scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
             w.copy_(((f / scale).to(torch.float8_e4m3fn).float() * scale).to(w.dtype))
-        for lw in self.w.layers:
-            for t in (lw.qkv_w, lw.o_w, lw.gate_up_w, lw.down_w):
-                fq(t)
+        for i, lw in enumerate(self.w.layers):
+            for kind, attr in self._rm_attr.items():
+                t = getattr(lw, attr)
+                if t is None:                           # freed: rebuilt from the fp8 copy on demand
+                    continue
+                tw = self.tiled[i].get(kind) if self.tiled is not None else None
+                if isinstance(tw, tuple):
+                    ops.untile_weights(tw, t.shape[0], t.shape[1], t.dtype, interleave_halves=(kind == "gu"), out=t)
+                else:
+                    fq(t)
 
     def _linear_tiled(self, x, w, N, **kw):
         """linear_tiled on a tiled weight of this runner (16-bit tensor, or (fp8 bytes, scales))."""
         if isinstance(w, tuple):
             return ops.linear_tiled_w8(x, w[0], w[1], N, **kw)
         return ops.linear_tiled(x, w, N, **kw)
+
+    def _rm(self, i: int, kind: str) -> torch.Tensor:
+        """Row-major [N, K] weight of projection `kind` (qkv / o / gu / down) of layer i for a library
+        GEMM.  Normally the stored matrix.  With a single weight copy it is rebuilt from the layer's
+        tiled (or fp8) copy into one scratch buffer per projection, in stream order: the GEMM that
+        follows reads it before the next layer's rebuild overwrites it."""
+        w = getattr(self.w.layers[i], self._rm_attr[kind])
+        if w is not None:
+            return w
+        n, k = self._rm_shape[kind]
+        buf = self._rm_scratch.get(kind)
+        if buf is None:
+            buf = self._rm_scratch[kind] = torch.empty(n, k, dtype=self.dtype, device=self.device)
+        return ops.untile_weights(self.tiled[i][kind], n, k, self.dtype, interleave_halves=(kind == "gu"), out=buf)
 
     def _tiled_plan(self, m: int):
         """{projection: (tiles_per_wg, k_groups)} of the projections that have a tiled kernel for m rows."""
@@ -339,7 +380,7 @@ class ModelRunner:
                 "qkv": (lambda t_, g_: lambda i: (lt(x, T[i]["qkv"], self.qw, partial=self.part_qkv, tiles_per_wg=t_,
                                                      k_groups=g_, epilogue=P),
                                                   attend(i, partial=self.part_qkv, num_slabs=g_, bias=W[i].qkv_b)),
-                        lambda i: (torch.mm(x, W[i].qkv_w.t(), out=qkv), attend(i, qkv=qkv))),
+                        lambda i: (torch.mm(x, self._rm(i, "qkv").t(), out=qkv), attend(i, qkv=qkv))),
                 "o": ((lambda t_, g_: lambda i: (lt(attn, T[i]["o"], self.H, partial=self.part_o, tiles_per_wg=t_,
                                                     k_groups=g_, epilogue=P),
                                                  ops.fused_add_rms_norm_partial(self.part_o, g_, resid, W[i].post_norm,
@@ -347,11 +388,11 @@ class ModelRunner:
                       if self.tp_size == 1 else
                       (lambda t_, g_: lambda i: (lt(attn, T[i]["o"], self.H, out=o, tiles_per_wg=t_),
                                                  ops.fused_add_rms_norm(o, resid, W[i].post_norm, eps, out=x))),
-                      lambda i: (torch.mm(attn, W[i].o_w.t(), out=o),
+                      lambda i: (torch.mm(attn, self._rm(i, "o").t(), out=o),
                                  ops.fused_add_rms_norm(o, resid, W[i].post_norm, eps, out=x))),
                 "gu": (lambda t_, g_: lambda i: lt(x, T[i]["gu"], 2 * self.F, out=act, tiles_per_wg=t_,
                                                    epilogue=ops.EPI_SILU_MUL),
-                       lambda i: (torch.mm(x, W[i].gate_up_w.t(), out=gu), ops.silu_and_mul(gu, out=act))),
+                       lambda i: (torch.mm(x, self._rm(i, "gu").t(), out=gu), ops.silu_and_mul(gu, out=act))),
                 "down": ((lambda t_, g_: lambda i: (lt(act, T[i]["down"], self.H, partial=self.part_dn, tiles_per_wg=t_,
                                                        k_groups=g_, epilogue=P),
                                                     ops.fused_add_rms_norm_partial(self.part_dn, g_, resid,
@@ -359,7 +400,7 @@ class ModelRunner:
                          if not self.mlp_sharded else
                          (lambda t_, g_: lambda i: (lt(act, T[i]["down"], self.H, out=dn, tiles_per_wg=t_),
                                                     ops.fused_add_rms_norm(dn, resid, W[i].input_norm, eps, out=x))),
-                         lambda i: (torch.mm(act, W[i].down_w.t(), out=dn),
+                         lambda i: (torch.mm(act, self._rm(i, "down").t(), out=dn),
                                     ops.fused_add_rms_norm(dn, resid, W[i].input_norm, eps, out=x))),
                 "lm_head": (lambda t_, g_: lambda i: ops.linear_tiled(x, self.lm_head_tiled, self.Vl,
                                                                       out=self.logits[:b], tiles_per_wg=t_),
@@ -462,9 +503,9 @@ class ModelRunner:
                                             bias=lw.qkv_b)
             else:
                 if lw.qkv_b is None:
-                    torch.mm(x, lw.qkv_w.t(), out=qkv)
+                    torch.mm(x, self._rm(i, "qkv").t(), out=qkv)
                 else:
-                    torch.addmm(lw.qkv_b, x, lw.qkv_w.t(), out=qkv)
+                    torch.addmm(lw.qkv_b, x, self._rm(i, "qkv").t(), out=qkv)
                 ops.paged_attn_decode_fused(qkv, self.cos_sin, slots, self.k_cache[i], self.v_cache[i], bt, ctx,
                                             self.nh, self.nkv, self.d, self.scale, num_splits=splits,
                                             workspace=self.attn_ws, out=attn)
@@ -475,13 +516,13 @@ class ModelRunner:
                 if mode["o"]:
                     self._linear_tiled(attn, tw["o"], self.H, out=o, tiles_per_wg=to)
                 else:
-                    torch.mm(attn, lw.o_w.t(), out=o)
+                    torch.mm(attn, self._rm(i, "o").t(), out=o)
                 self._allreduce(o)
                 ops.fused_add_rms_norm(o, resid, lw.post_norm, self.eps, out=x)
             if mode["gu"]:
                 self._linear_tiled(x, tw["gu"], 2 * self.F, out=act, tiles_per_wg=tg, epilogue=ops.EPI_SILU_MUL)
             else:
-                torch.mm(x, lw.gate_up_w.t(), out=gu)
+                torch.mm(x, self._rm(i, "gu").t(), out=gu)
                 ops.silu_and_mul(gu, out=act)
             if mode["down"] and slabs_dn:
                 self._linear_tiled(act, tw["down"], self.H, partial=self.part_dn, tiles_per_wg=td, k_groups=gd,
@@ -490,7 +531,7 @@ class ModelRunner:
                 if mode["down"]:
                     self._linear_tiled(act, tw["down"], self.H, out=dn, tiles_per_wg=td)
                 else:
-                    torch.mm(act, lw.down_w.t(), out=dn)
+                    torch.mm(act, self._rm(i, "down").t(), out=dn)
                 if self.mlp_sharded:
                     self._allreduce(dn)
         add_mlp_and_norm(self.w.final_norm)
@@ -600,16 +641,16 @@ class ModelRunner:
             else:
                 ops.fused_add_rms_norm(dn, resid, lw.input_norm, self.eps, out=x)
             if lw.qkv_b is None:
-                torch.mm(x, lw.qkv_w.t(), out=qkv)
+                torch.mm(x, self._rm(i, "qkv").t(), out=qkv)
             else:
-                torch.addmm(lw.qkv_b, x, lw.qkv_w.t(), out=qkv)
+                torch.addmm(lw.qkv_b, x, self._rm(i, "qkv").t(), out=qkv)
             attend(i, qkv, attn)
-            torch.mm(attn, lw.o_w.t(), out=o)
+            torch.mm(attn, self._rm(i, "o").t(), out=o)
             self._allreduce(o)
             ops.fused_add_rms_norm(o, resid, lw.post_norm, self.eps, out=x)
-            torch.mm(x, lw.gate_up_w.t(), out=gu)
+            torch.mm(x, self._rm(i, "gu").t(), out=gu)
             ops.silu_and_mul(gu, out=act)
-            torch.mm(act, lw.down_w.t(), out=dn)
+            torch.mm(act, self._rm(i, "down").t(), out=dn)
             if self.mlp_sharded:
                 self._allreduce(dn)
         return dn

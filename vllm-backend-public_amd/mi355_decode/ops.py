@@ -615,6 +615,30 @@ def tile_weights(weight: torch.Tensor, interleave_halves: bool = False) -> torch
     return out
 
 
+def untile_weights(w_tiled, N: int, K: int, dtype: torch.dtype, interleave_halves: bool = False,
+                   out: torch.Tensor | None = None) -> torch.Tensor:
+    """Row-major [N, K] matrix from a tiled weight: a 16-bit tensor of tile_weights (the same bits
+    back), or the (fp8 bytes, row scales) pair of tile_weights_fp8 (decoded: round(fp8 * scale))."""
+    fp8 = isinstance(w_tiled, tuple)
+    src = w_tiled[0] if fp8 else w_tiled
+    _dev(src, "w_tiled")
+    if dtype not in _DT:
+        raise TypeError(f"dtype {dtype} not supported")
+    want = int(lib.mi355_tiled_weight_fp8_bytes(N, K)) if fp8 else int(lib.mi355_tiled_weight_elems(N, K))
+    if want == 0 or src.numel() != want or (not fp8 and src.dtype != dtype) or (fp8 and src.dtype != torch.uint8):
+        raise ValueError("w_tiled does not match (N, K) / dtype")
+    if out is None:
+        out = torch.empty((N, K), dtype=dtype, device=src.device)
+    elif out.dtype != dtype or tuple(out.shape) != (N, K) or not out.is_contiguous():
+        raise ValueError("out must be contiguous [N, K] in the model dtype")
+    if fp8:
+        check(lib.mi355_untile_weights_fp8(out.data_ptr(), src.data_ptr(), w_tiled[1].data_ptr(), N, K,
+                                           int(bool(interleave_halves)), _DT[dtype], _stream()))
+    else:
+        check(lib.mi355_untile_weights(out.data_ptr(), src.data_ptr(), N, K, int(bool(interleave_halves)), _stream()))
+    return out
+
+
 def linear_tiled(x: torch.Tensor, w_tiled: torch.Tensor, N: int, bias: torch.Tensor | None = None,
                  out: torch.Tensor | None = None, partial: torch.Tensor | None = None, tiles_per_wg: int = 0,
                  k_groups: int = 1, epilogue: int = EPI_STORE):
