@@ -330,8 +330,8 @@ class ModelRunner:
                 for i in range(self.L):
                     fn(i)
         g.replay()
-        best = float("inf")                               # fastest of three replays: least disturbed by other work
-        for _ in range(3):
+        best = float("inf")                               # fastest of five replays: least disturbed by other work
+        for _ in range(5):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             g.replay()
@@ -419,7 +419,10 @@ class ModelRunner:
                             us = self._time_launches(tiled_form(*cand))
                         except Mi355Error:                  # no kernel of this form for the code (e.g. fp8 with 108)
                             continue
-                        if best_us is None or us < 0.98 * best_us:      # the planner's own choice unless clearly beaten
+                        # the planner's own choice unless beaten by more than the timing's repeatability
+                        # (replays of one graph agree to ~0.3 %; a 2 % margin here left a form that is
+                        # 2 % faster -- down_proj split over 8 K groups, 1.8 % of the whole step -- to chance)
+                        if best_us is None or us < 0.99 * best_us:
                             best, best_us = cand, us
                     if best_us is None:
                         best_us = self._time_launches(tiled_form(*best))
