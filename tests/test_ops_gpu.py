@@ -235,6 +235,52 @@ def test_rope_kv_write(ops, dtype, nh, kvh, d):
     np.testing.assert_array_equal(host(vc), vc_ref)
 
 
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("nh,kvh,d", [(8, 2, 128), (32, 8, 128), (7, 1, 64), (4, 4, 256)])
+def test_rope_kv_write_prefill_sized(ops, dtype, nh, kvh, d):
+    """>= 64 tokens: the V heads go through the page-transposing kernel.  Packed sequences whose
+    16-token groups fill pages in order (whole-page 16-byte stores), a sequence that starts
+    mid-page and one whose length is not a multiple of 16 (groups straddle sequences and pages:
+    element-wise stores), padding slots, a slot beyond the cache, pages in shuffled order, and a
+    token count that is not a multiple of 16 -- all bit-exact against the oracle; untouched
+    pages stay as they were."""
+    rng = rng_for("rope-prefill", dtype, nh, kvh, d)
+    nblk, max_pos = 64, 1024
+    pages = list(rng.permutation(nblk - 1))                     # the last page stays untouched
+    slots, pos = [], []
+
+    def seq(start, n):
+        blocks = [pages.pop() for _ in range((start + n + 15) // 16)]
+        for p_ in range(start, start + n):
+            slots.append(blocks[p_ // 16] * 16 + p_ % 16)
+            pos.append(p_)
+
+    seq(0, 128)           # aligned: eight whole pages
+    seq(0, 48)
+    seq(5, 40)            # chunk that starts mid-page
+    seq(0, 37)            # length not a multiple of 16: the groups after it straddle sequences
+    seq(0, 64)
+    slots, pos = np.asarray(slots, np.int64), np.asarray(pos, np.int64)
+    slots[200] = -1                                            # padding token inside an otherwise whole page
+    slots[130] = nblk * 16 + 3                                 # beyond the cache: dropped
+    T = len(slots)
+    assert T % 16 != 0 and T >= 64
+    table = R.rope_cos_sin_table(max_pos, d, 5e5, dtype)
+    qkv = grid(rng, (T, (nh + 2 * kvh) * d), dtype)
+    kc_ref = np.full((nblk, kvh, 16, d), 0.5, np.float32)
+    vc_ref = np.full((nblk, kvh, d, 16), 0.5, np.float32)
+    ref_slots = np.where(slots >= nblk * 16, -1, slots)
+    ref = R.rope_kv_write(qkv, pos, table, ref_slots, kc_ref, vc_ref, nh, kvh, d, dtype)
+    kc, vc = make_cache(nblk, kvh, d, dtype, fill=0.5)
+    qd = dev(qkv, dtype)
+    ops.rope_kv_write(qd, torch.from_numpy(pos).cuda(), dev(table, dtype), torch.from_numpy(slots).cuda(),
+                      kc, vc, nh, kvh, d)
+    np.testing.assert_array_equal(host(qd), ref)
+    np.testing.assert_array_equal(host(kc), kc_ref)
+    np.testing.assert_array_equal(host(vc), vc_ref)
+    assert (host(vc)[nblk - 1] == 0.5).all()
+
+
 def test_rope_golden(ops, ops_golden):
     """HF apply_rotary_pos_emb outputs (bf16), using HF's own cos/sin rows as the table."""
     g = ops_golden

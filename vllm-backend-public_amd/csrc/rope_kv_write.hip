@@ -11,6 +11,15 @@
 // precomputed table in the model dtype.  HBM-bound and small: 2 bytes in, 2 out
 // per q element, 2 in / 4 out per k element, 2 in / 2 out per v element.
 //
+// Prefill-sized calls (>= 64 tokens, plain form) store V with a second kernel instead
+// (v_pages_kernel): a wave takes 16 consecutive packed tokens of one kv head, and when
+// they fill one page in order -- the usual case, a prompt's tokens go to consecutive
+// slots -- it transposes the 16 x head_dim tile through LDS and writes the page as
+// one contiguous 32 * head_dim bytes (16-byte stores) instead of 16 * head_dim two-byte
+// stores at a 32-byte stride, which the cache then has to merge sector by sector.
+// Any other group (page boundary inside, padding slots, a chunk that starts mid-page)
+// takes the element-wise stores.
+//
 // The PART form reads the projection from the fp32 partial-sum slabs of a
 // K-split GEMM ([slab][token][width]) instead: qkv = round(slab_0 + slab_1 + ...
 // + bias) is formed on the fly, and q, k (rotated) and v are all written to the
@@ -25,7 +34,7 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(
     const uint16_t* __restrict__ cos_sin, int max_position, const int64_t* __restrict__ slot_mapping,
     uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache, int num_blocks, int64_t num_tokens,
     int num_heads, int num_kv_heads, int head_dim, const float* __restrict__ partial, int num_slabs,
-    int64_t slab_stride, const uint16_t* __restrict__ bias) {
+    int64_t slab_stride, const uint16_t* __restrict__ bias, int skip_v) {
   const int half = head_dim >> 1;
   const int chunks = half >> 3;  // 8 pairs per chunk
   const int heads_total = num_heads + 2 * num_kv_heads;
@@ -37,6 +46,7 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(
     const int c = static_cast<int>(it % chunks);
     const int head = static_cast<int>((it / chunks) % heads_total);
     const int64_t tok = it / (static_cast<int64_t>(chunks) * heads_total);
+    if (skip_v && head >= num_heads + num_kv_heads) continue;   // v_pages_kernel stores the V heads
 
     uint16_t* base = qkv + tok * qkv_stride + static_cast<int64_t>(head) * head_dim;
     uint4* p1 = reinterpret_cast<uint4*>(base + 8 * c);
@@ -130,6 +140,64 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(
   }
 }
 
+// V heads of a prefill-sized call: one wave per (16 packed tokens, kv head).
+constexpr int kVPitch = 48;   // LDS bytes per head_dim row of the transposed tile: 16 tokens x 2 B + padding, 16-byte aligned
+
+__global__ __launch_bounds__(256) void v_pages_kernel(const uint16_t* __restrict__ qkv, int64_t qkv_stride,
+                                                      const int64_t* __restrict__ slot_mapping,
+                                                      uint16_t* __restrict__ v_cache, int num_blocks, int64_t num_tokens,
+                                                      int num_heads, int num_kv_heads, int head_dim) {
+  constexpr int BS = MI355_BLOCK_SIZE;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_all[4 * 256 * kVPitch];   // per wave: head_dim (<= 256) rows
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  unsigned char* lds = lds_all + wave * (256 * kVPitch);
+  const int t = lane & 15, p0 = lane >> 4;
+  const int pieces = head_dim >> 3;                       // 16-byte pieces per token row
+  const int64_t groups = (num_tokens + 15) >> 4;
+  const int64_t tiles = groups * num_kv_heads;
+  const int64_t slots_total = static_cast<int64_t>(num_blocks) * BS;
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wave; tile < tiles; tile += static_cast<int64_t>(gridDim.x) * 4) {
+    const int kvh = static_cast<int>(tile % num_kv_heads);
+    const int64_t tok = (tile / num_kv_heads) * 16 + t;
+    const bool valid = tok < num_tokens;
+    const int64_t slot = valid ? MI355_LD(int64_t, slot_mapping, slot_mapping + tok) : -1;
+    const int64_t slot0 = __shfl(slot, 0, 64);
+    const bool in_order = valid && slot == slot0 + t;
+    const bool full = __all(in_order) && slot0 >= 0 && (slot0 % BS) == 0 && slot0 + BS <= slots_total;   // wave-uniform
+    const uint16_t* src = qkv + (valid ? tok : 0) * qkv_stride + static_cast<int64_t>(num_heads + num_kv_heads + kvh) * head_dim;
+    if (full) {
+      for (int piece = p0; piece < pieces; piece += 4) {
+        const uint4 v = MI355_LD(uint4, qkv, src + 8 * piece);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          *reinterpret_cast<uint16_t*>(lds + (8 * piece + e) * kVPitch + 2 * t) =
+              static_cast<uint16_t>(e & 1 ? w[e >> 1] >> 16 : w[e >> 1] & 0xFFFFu);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // the page of this kv head: head_dim rows of 16 tokens, 32 * head_dim contiguous bytes
+      uint16_t* page = v_cache + ((slot0 / BS) * num_kv_heads + kvh) * static_cast<int64_t>(head_dim) * BS;
+      for (int q = lane; q < 2 * head_dim; q += 64) {    // 16-byte piece q: row q / 2, tokens 8 * (q % 2) .. + 8
+        const uint4 v = *reinterpret_cast<const uint4*>(lds + (q >> 1) * kVPitch + (q & 1) * 16);
+        MI355_ST(uint4, v_cache, page + static_cast<int64_t>(q) * 8, v);
+      }
+      __builtin_amdgcn_wave_barrier();                   // the next tile of this wave overwrites the LDS rows
+    } else if (valid && slot >= 0 && slot < slots_total) {
+      uint16_t* dst = v_cache + ((slot / BS) * num_kv_heads + kvh) * static_cast<int64_t>(head_dim) * BS + (slot % BS);
+      for (int piece = p0; piece < pieces; piece += 4) {
+        const uint4 v = MI355_LD(uint4, qkv, src + 8 * piece);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          MI355_ST(uint16_t, v_cache, dst + static_cast<int64_t>(8 * piece + e) * BS,
+                   static_cast<uint16_t>(e & 1 ? w[e >> 1] >> 16 : w[e >> 1] & 0xFFFFu));
+      }
+    }
+  }
+}
+
 template <bool PART>
 static int32_t launch_rope(const char* name, void* qkv, int64_t qkv_stride, const int64_t* positions,
                            const void* cos_sin, int32_t max_position, const int64_t* slot_mapping, void* k_cache,
@@ -168,18 +236,27 @@ static int32_t launch_rope(const char* name, void* qkv, int64_t qkv_stride, cons
   if (blocks > 8192) blocks = 8192;  // grid-stride beyond 32 workgroups per CU
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  const int skip_v = (!PART && num_tokens >= 64) ? 1 : 0;   // prefill-sized: the V heads go through v_pages_kernel
   if (dtype == MI355_BF16)
     hipLaunchKernelGGL((rope_kv_write_kernel<BF16, PART>), grid, block, 0, s, static_cast<uint16_t*>(qkv),
                        qkv_stride, positions, static_cast<const uint16_t*>(cos_sin), max_position,
                        slot_mapping, static_cast<uint16_t*>(k_cache), static_cast<uint16_t*>(v_cache),
                        num_blocks, num_tokens, num_heads, num_kv_heads, head_dim, partial, num_slabs,
-                       slab_stride, static_cast<const uint16_t*>(bias));
+                       slab_stride, static_cast<const uint16_t*>(bias), skip_v);
   else
     hipLaunchKernelGGL((rope_kv_write_kernel<F16, PART>), grid, block, 0, s, static_cast<uint16_t*>(qkv),
                        qkv_stride, positions, static_cast<const uint16_t*>(cos_sin), max_position,
                        slot_mapping, static_cast<uint16_t*>(k_cache), static_cast<uint16_t*>(v_cache),
                        num_blocks, num_tokens, num_heads, num_kv_heads, head_dim, partial, num_slabs,
-                       slab_stride, static_cast<const uint16_t*>(bias));
+                       slab_stride, static_cast<const uint16_t*>(bias), skip_v);
+  if (skip_v) {
+    const int64_t tiles = ((num_tokens + 15) / 16) * num_kv_heads;
+    int64_t vblocks = (tiles + 3) / 4;
+    if (vblocks > 8192) vblocks = 8192;
+    hipLaunchKernelGGL(v_pages_kernel, dim3(static_cast<unsigned>(vblocks)), dim3(256), 0, s,
+                       static_cast<const uint16_t*>(qkv), qkv_stride, slot_mapping, static_cast<uint16_t*>(v_cache),
+                       num_blocks, num_tokens, num_heads, num_kv_heads, head_dim);
+  }
   return check_launch(name);
 }
 
