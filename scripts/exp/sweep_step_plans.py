@@ -49,11 +49,14 @@ def step_ms(plans):
 cur = dict(r._tiled_plan(bucket))
 base = step_ms(cur)
 print(json.dumps({"start": {k: list(v) for k, v in cur.items()}, "step_ms": round(base, 4)}), flush=True)
-for kind in ("down", "o", "qkv", "gu", "lm_head"):
+import os
+kinds = os.environ.get("SWEEP_KINDS", "down,o,qkv,gu,lm_head").split(",")
+max_qkv = int(os.environ.get("SWEEP_QKV_MAX_SLABS", r.QKV_MAX_SLABS))
+for kind in kinds:
     n, kk, split = r.tiled_shapes[kind]
     rows = []
     for cand in ops.linear_tiled_candidates(n, kk, split, B, swiglu=(kind == "gu")):
-        if kind == "qkv" and cand[1] > r.QKV_MAX_SLABS:
+        if kind == "qkv" and cand[1] > max_qkv:
             continue
         t = step_ms({**cur, kind: cand})
         rows.append((list(cand), None if t is None else round(t, 4)))

@@ -8,9 +8,11 @@
 // length).  The workgroup walks the keys its tile can see in 32-token steps.  The
 // K and V pages of a step are STAGED THROUGH LDS ONCE PER WORKGROUP, double buffered: all 256
 // threads copy the two pages (coalesced 16-byte pieces, whole 4 KB pages) into an LDS image
-// in FRAGMENT ORDER -- piece (fragment, lane) at (fragment*64 + lane)*16, so every wave's
-// `ds_read_b128` of an MFMA A operand is lane-linear and conflict-free -- while the waves
-// compute on the other buffer; one workgroup barrier per step.  The query fragments (B
+// in FRAGMENT ORDER -- piece (fragment, lane) at (fragment*64 + lane)*16 for V, the same with
+// the slots of each 16-lane block XOR-swizzled for K (see KFRAG below) -- so every wave's
+// `ds_read_b128` of an MFMA A operand and every staging `ds_write_b128` is conflict-free;
+// two steps are staged per barrier interval while the waves compute on the other pair of
+// images: one workgroup barrier per 64 tokens.  The query fragments (B
 // operands) stay in registers.  Softmax in ONE pass over the keys with a LAZILY updated exponent
 // reference: p = exp2(s*scale - m_ref), where m_ref is a column's maximum as of the last time
 // it was brought up to date.  A step only checks, lane by lane and with no cross-lane traffic,
@@ -30,7 +32,6 @@
 
 #include <math.h>
 #include <stdlib.h>
-#include <type_traits>
 
 namespace mi355 {
 
@@ -69,9 +70,8 @@ __global__ __launch_bounds__(kPrefillThreads, NQ <= 2 ? 2 : 1) void paged_attn_p
   constexpr int PIECES = 8 * D;                  // 16-byte pieces per step: two K pages + two V pages
   constexpr int PPT = PIECES / kPrefillThreads;  // per thread: 4 (D = 128) or 2 (D = 64)
   static_assert(PIECES % kPrefillThreads == 0, "whole pieces per thread");
-  // HS 32-token images per barrier interval, two intervals in flight: half as many workgroup
-  // barriers per key as with one image, and the second image's QK^T can run under the first one's
-  // exponentials (independent instruction streams inside one basic block)
+  // HS 32-token images per barrier interval, two such sets (one computed on, one being staged):
+  // half as many workgroup barriers per key as with one image per interval
   constexpr int HS = 2;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HS * BUF];
 
