@@ -242,6 +242,23 @@ def test_prompt_normalisation_and_detokenizer():
     ids = tok.encode("héllo")                               # multi-byte char split over two tokens
     out = "".join(d.push([i]) for i in ids)
     assert out == "héllo"
+    # the windowed decode emits exactly the text of the whole sequence, whatever the chunking
+    import random
+    rnd = random.Random(0)
+    for _ in range(100):
+        text = "".join(rnd.choice(["a", "é", "漢", "😀", " ", "z", "\n", "ß"]) for _ in range(rnd.randint(1, 60)))
+        ids = tok.encode(text)
+        d, out, i = IncrementalDetokenizer(tok), "", 0
+        while i < len(ids):
+            n = rnd.randint(1, 3)
+            out += d.push(ids[i:i + n], final=i + n >= len(ids))
+            i += n
+        assert out == text
+    for _ in range(100):                                      # arbitrary bytes: the final text is the full decode
+        ids = [rnd.randrange(3, 259) for _ in range(rnd.randint(1, 40))]
+        d = IncrementalDetokenizer(tok)
+        out = "".join(d.push([t], final=k == len(ids) - 1) for k, t in enumerate(ids))
+        assert out == tok.decode(ids)
 
 
 def test_echo_with_logprobs_scores_the_prompt():

@@ -63,18 +63,27 @@ def load_tokenizer(model: str, vocab_size: int):
 
 
 class IncrementalDetokenizer:
-    """Text delta per new token; holds back bytes of an unfinished UTF-8 sequence."""
+    """Text delta per new token; holds back bytes of an unfinished UTF-8 sequence.  Each push
+    decodes a window of the last few tokens, not the whole sequence (that made a generation of n
+    tokens cost n^2 / 2 token decodes on the server's event loop): the window starts a few tokens
+    before the text already emitted, so that a tokenizer whose pieces depend on their neighbours
+    (leading-space markers) decodes the new tokens in context, and the delta is what the window's
+    text grew by."""
+    CONTEXT = 5
 
     def __init__(self, tokenizer):
         self.tk = tokenizer
         self.ids: List[int] = []
-        self.text = ""
+        self.prefix = 0        # window start
+        self.read = 0          # tokens whose text has been emitted
 
     def push(self, new_ids: List[int], final: bool = False) -> str:
         self.ids.extend(new_ids)
-        full = self.tk.decode(self.ids)
-        if full.endswith("\ufffd") and not final:
+        before = self.tk.decode(self.ids[self.prefix:self.read]) if self.read > self.prefix else ""
+        now = self.tk.decode(self.ids[self.prefix:])
+        if now.endswith("\ufffd") and not final:            # an unfinished multi-byte character: wait for the rest
             return ""
-        delta = full[len(self.text):]
-        self.text = full
+        delta = now[len(before):]
+        self.read = len(self.ids)
+        self.prefix = max(self.read - self.CONTEXT, 0)
         return delta
