@@ -52,7 +52,7 @@ class EngineThread:
         self.thread = threading.Thread(target=self._run, name="mi355-engine", daemon=True)
         self.sink_loops = {}                 # request_id -> asyncio loop its sink must run on (or absent)
         import os
-        self.admission_window = float(os.environ.get("MI355_ADMISSION_WINDOW_MS", "1.0")) * 1e-3
+        self.admission_window = float(os.environ.get("MI355_ADMISSION_WINDOW_MS", "2.0")) * 1e-3
         self.admission_cap = float(os.environ.get("MI355_ADMISSION_CAP_MS", "20.0")) * 1e-3
         self.steps = 0
         self.tokens_out = 0
@@ -91,7 +91,10 @@ class EngineThread:
                 msgs.append(self.inbox.get_nowait())
         except queue.Empty:
             pass
-        # Admission window: requests of one client burst arrive a fraction of a millisecond apart;
+        # Admission window: requests of one client burst arrive a fraction of a millisecond apart
+        # (now and then more than a millisecond: the HTTP thread shares the interpreter with this
+        # one -- with a 1 ms window two of five 32-request bursts were split, which costs the late
+        # half a whole prefill step of latency; 2 ms costs every burst 1 ms);
         # prefilling each as it lands would stagger the batch over several prefill steps.  While
         # new requests keep arriving within `admission_window` of each other (and for at most
         # `admission_cap` in all) the engine waits for the rest of the burst before it schedules.
