@@ -288,8 +288,9 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   if (EPI == EPI_REDUCE_STORE || EPI == EPI_REDUCE_RESID) {
     // The slabs cross workgroups (and XCDs, whose L2s are not coherent with each other)
     // inside one launch.  They are written and read with device-scope atomic accesses,
-    // which go past the non-coherent cache levels one access at a time; a device-scope
-    // fence instead would write back and invalidate the whole L2 (measured: +35 us).
+    // which go past the non-coherent cache levels one access at a time (a device-scope
+    // fence executed by every wave around plain accesses measured +35 us); ONE lane per
+    // workgroup still fences at device scope around the ticket, see below.
     const int kgs = gridDim.y;
     if (live) {
 #pragma unroll
@@ -303,12 +304,25 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
             __hip_atomic_store(pp + r, acc[m][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // every lane's slab stores have completed ...
-    __syncthreads();                                          // ... before one lane draws the ticket
-    if (tid == 0)
+    // Hand-off to the workgroup that will sum the slabs (it may run on another XCD): every wave
+    // waits for its slab stores, then ONE lane makes them visible device-wide (agent-scope
+    // release) before it draws the ticket; the workgroup that draws the last ticket acquires at
+    // agent scope before anyone in it reads a slab.  (With only a workgroup-scope fence before
+    // the ticket the last workgroup now and then summed a slab that had not arrived yet: one
+    // 4-column strip wrong in about one run of the test suite in five.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       last_s = MI355_OK_AT(fa.counters, fa.counters + blockIdx.x, 4) &&
                __hip_atomic_fetch_add(&fa.counters[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
                    static_cast<unsigned>(kgs - 1);
+      if (last_s) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
     __syncthreads();
     if (!last_s) return;
     if (tid == 0) MI355_ST(unsigned, fa.counters, fa.counters + blockIdx.x, 0u);   // all tickets drawn: re-arm for the next launch
