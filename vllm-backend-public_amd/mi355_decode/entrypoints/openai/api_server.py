@@ -141,16 +141,20 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
                         lines.append(f'mi355_gemm_form{{bucket="{bucket}",projection="{proj}"}} {int(bool(tiled))}')
         return Response("\n".join(lines) + "\n", media_type="text/plain")
 
-    @app.post("/v1/completions")
+    # The two generation routes are plain Starlette routes (request in, response out): the framework's
+    # per-request dependency / body-model machinery has nothing to do here and costs a burst of 32
+    # requests several milliseconds of time to first token on the one thread that parses them.
     async def completions(request: Request):
         return await serve(request, chat=False)
 
-    @app.post("/v1/chat/completions")
     async def chat_completions(request: Request):
         """Chat form of the same generation path: the messages are rendered to one prompt (the model
         directory's chat template when it has one, a plain role-tagged transcript otherwise) and the
         answer comes back as an assistant message (`chat.completion` / `chat.completion.chunk`)."""
         return await serve(request, chat=True)
+
+    app.add_route("/v1/completions", completions, methods=["POST"])
+    app.add_route("/v1/chat/completions", chat_completions, methods=["POST"])
 
     async def serve(request: Request, chat: bool):
         bad = not_ready()
