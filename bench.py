@@ -460,6 +460,16 @@ def served_path(engine, cfg, a, batch):
         thread.thread.join(timeout=10)
         results.shutdown()
     out["results_stored"] = [f"{path} pk={pk}" for path, pk in stored]
+    full = [b for b in thread.bursts if b[0] == batch][-a.served_runs:]
+    if full:
+        import statistics
+        out["ttft_breakdown_ms_p50"] = {
+            "requests_arrive_over": round(statistics.median(b[1] for b in full), 2),
+            "engine_waits_for_stragglers": round(statistics.median(b[2] for b in full), 2),
+            "note": "server side, per burst admitted in one piece: first to last request handed to the engine (HTTP "
+                    "parsing on one thread), then the admission window; the rest of TTFT is the prefill step and the "
+                    "first SSE event's way back"}
+        out["bursts_admitted_whole"] = f"{len(full)} of {a.served_runs}"
     out["path"] = ("client process -> HTTP/SSE (uvicorn) -> engine thread -> HIP-graph decode steps; tokenizer: "
                    "byte-wise stand-in (no tokenizer.json for synthetic weights), one SSE event per token")
     return out

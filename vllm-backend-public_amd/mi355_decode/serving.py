@@ -54,6 +54,7 @@ class EngineThread:
         import os
         self.admission_window = float(os.environ.get("MI355_ADMISSION_WINDOW_MS", "2.0")) * 1e-3
         self.admission_cap = float(os.environ.get("MI355_ADMISSION_CAP_MS", "20.0")) * 1e-3
+        self.bursts = []                     # (requests, arrival spread ms, wait after the last arrival ms) of recent admissions
         self.steps = 0
         self.tokens_out = 0
         self.started = time.time()
@@ -109,6 +110,11 @@ class EngineThread:
                 msgs.append(m)
                 if m is None:
                     break
+        adds = [m.arrival for m in msgs if isinstance(m, _Add)]
+        if adds:          # how long the burst took to arrive and how long the engine then waited for more of it
+            now = time.perf_counter()
+            self.bursts.append((len(adds), (max(adds) - min(adds)) * 1e3, (now - max(adds)) * 1e3))
+            del self.bursts[:-64]
         return msgs
 
     def _exchange(self, msgs: list) -> list:
@@ -155,6 +161,13 @@ class EngineThread:
     def _run(self):
         try:
             self.engine = self._make_engine()
+            # Everything allocated so far (weights' Python objects, kernels' bindings, the HTTP app)
+            # lives as long as the server: moved out of the collector's reach, so that a full
+            # collection -- tens of milliseconds over a few million objects, in whichever thread
+            # happens to allocate -- cannot land in the middle of a burst of requests or a decode step.
+            import gc
+            gc.collect()
+            gc.freeze()
             self.ready.set()
             eng = self.engine
             while True:
