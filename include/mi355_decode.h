@@ -356,10 +356,13 @@ int32_t mi355_argmax_key_to_index(int64_t* out_ids, const int64_t* keys,
  * CDF.  All of it is fixed-order fp32 arithmetic: a (logits, parameters, seed,
  * step) tuple always yields the same token, on any launch.  Rows with
  * temperature[b] <= 0 get the greedy token (mi355_argmax semantics); a row that
- * holds a NaN yields the index of its first NaN from either.  NOTE the candidate
- * set never exceeds the 1024 most likely tokens: top_k <= 0 ("disabled") samples
- * from those 1024, not from the whole vocabulary (the tail beyond them carries a
- * negligible mass for a trained model; the server rejects top_k > 1024).  Serves
+ * holds a NaN yields the index of its first NaN from either.  A row with neither
+ * cut (top_k[b] <= 0 and top_p[b] >= 1) draws from the WHOLE vocabulary, in the
+ * Gumbel-max form: token = argmax_i(logit_i / temperature[b] - ln(-ln(u_i))) with
+ * one uniform u_i per (seeds[b], steps[b], i) from the same counter hash, ties to
+ * the lowest index, the same fixed-order fp32 arithmetic.  With a cut the candidate
+ * set never exceeds the 1024 most likely tokens: top_p < 1 with top_k <= 0 keeps a
+ * nucleus inside those 1024 (the server rejects top_k > 1024).  Serves
  * temperature/top_k/top_p/seed of POST /v1/completions
  * (benchmark-deployer/docs/deployment/post_run.md:46).
  */

@@ -666,6 +666,59 @@ def test_sample_distribution(ops):
     assert np.abs(freq - p).max() < 4 * np.sqrt(p.max() / n) + 0.01
 
 
+@pytest.mark.parametrize("ldt", ["float32", "bfloat16", "float16"])
+@pytest.mark.parametrize("B,V", [(7, 1000), (32, 128256), (3, 72)])
+def test_sample_full_vocabulary(ops, ldt, B, V):
+    """top_k disabled and top_p >= 1: the Gumbel-max draw over the whole row, bit-exact."""
+    rng = rng_for("sample-full", ldt, B, V)
+    lg = R.round_to((rng.standard_normal((B, V)) * 2).astype(np.float32), ldt)
+    lg[0, :] = 0.0                                          # all tied: a uniform draw
+    lg[0, 5] = -0.0
+    lg[1, :] = -np.inf                                      # one finite logit among -inf
+    lg[1, V - 1] = -2.5
+    lg[2, 7] = np.nan                                       # a NaN wins, lowest index first
+    lg[2, 40] = np.nan
+    if B > 3:
+        lg[3, 11] = np.inf
+        lg[4, :] = -np.inf                                  # nothing finite: index 0
+    temperature = rng.choice([0.05, 0.7, 1.0, 1.5, 30.0], B).astype(np.float32)
+    top_k = rng.choice([-1, 0], B).astype(np.int32)
+    top_p = rng.choice([1.0, 1.5], B).astype(np.float32)
+    seeds = rng.integers(-2 ** 62, 2 ** 62, B).astype(np.int64)
+    tdt = {"float32": torch.float32, **DT}[ldt]
+    lgd = torch.from_numpy(lg).to(tdt).cuda()
+    for step in (0, 3, 2 ** 40):
+        steps = np.full(B, step, np.int64) + np.arange(B)
+        ref = R.sample_topk_topp(lg, temperature, top_k, top_p, seeds, steps)
+        out = ops.sample(lgd, torch.from_numpy(temperature).cuda(), torch.from_numpy(top_k).cuda(),
+                         torch.from_numpy(top_p).cuda(), torch.from_numpy(seeds).cuda(), torch.from_numpy(steps).cuda())
+        np.testing.assert_array_equal(out.cpu().numpy(), ref)
+        assert out[1].item() == V - 1 and out[2].item() == 7
+        if B > 3:
+            assert out[3].item() == 11 and out[4].item() == 0
+
+
+def test_sample_full_vocabulary_distribution(ops):
+    """With no cut, tokens beyond the 1024 most likely ones are drawn with their softmax mass."""
+    rng = rng_for("sample-full-dist")
+    V, T, n = 8192, 1.3, 8192
+    row = R.round_to((rng.standard_normal(V) * 0.5).astype(np.float32), "bfloat16")
+    row[:8] += 4.0
+    row = R.round_to(row, "bfloat16")
+    lg = torch.from_numpy(np.tile(row, (n, 1))).to(torch.bfloat16).cuda()
+    out = ops.sample(lg, torch.full((n,), T, device="cuda"), torch.full((n,), -1, dtype=torch.int32, device="cuda"),
+                     torch.ones(n, device="cuda"), torch.arange(n, device="cuda") * 7919 + 3,
+                     torch.arange(n, device="cuda") % 101).cpu().numpy()
+    p = np.exp(row.astype(np.float64) / T)
+    p /= p.sum()
+    tail = np.zeros(V, bool)
+    tail[np.argsort(-row, kind="stable")[1024:]] = True
+    assert p[tail].sum() > 0.3
+    assert abs(tail[out].mean() - p[tail].sum()) < 4 * np.sqrt(p[tail].sum() / n)
+    for t in range(8):
+        assert abs((out == t).mean() - p[t]) < 4 * np.sqrt(p[t] / n) + 1e-3
+
+
 # --------------------------------------------------------------------------- #
 # decode-time linear layer on fragment-tiled weights
 # --------------------------------------------------------------------------- #

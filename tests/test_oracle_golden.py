@@ -217,3 +217,57 @@ def test_fp8_e4m3fn_rounding_matches_torch():
     q, s = R.quantize_rows_fp8(np.array([[0.0, 0.0], [1.0, -3.5], [448.0, 2.0]], np.float32))
     np.testing.assert_array_equal(s, np.array([1.0, 3.5 / 448, 1.0], np.float32))
     assert np.abs(q).max() == 448.0 and (q[0] == 0).all()
+
+
+# --------------------------------------------------------------------------- #
+# random sampling, full-vocabulary form: the pieces of the restatement against numpy's own
+# log / softmax (no engine output pins the drawn tokens themselves: parity unpinned; what is
+# pinned is that the draw follows softmax(logits / T) and that the GPU equals this code)
+# --------------------------------------------------------------------------- #
+def test_ln_det_is_a_natural_logarithm():
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(5e-8, 20, 200000), 1 - 2.0 ** -np.arange(1, 25), 2.0 ** -np.arange(0, 25),
+                        [np.sqrt(2), 1.41421354, 1.4142137]]).astype(np.float32)
+    got = R.ln_det(x).astype(np.float64)
+    want = np.log(x.astype(np.float64))
+    assert np.abs(got - want).max() <= 1e-6
+    assert (np.abs(got - want) <= 4e-7 * np.abs(want) + 1e-9).all()
+
+
+def test_sample_uniform_at_stays_inside_the_open_interval():
+    for h in (0, 1, 0xFFFFFFFF, 0x9E3779B9):
+        u = R.sample_uniform_at(h, 200000)
+        assert u.dtype == np.float32 and u.min() >= 2.0 ** -24 and u.max() <= 1 - 2.0 ** -24
+        assert abs(float(u.mean()) - 0.5) < 0.01
+        g = -R.ln_det(-R.ln_det(u))
+        assert np.isfinite(g).all()
+    # the vectorised hash is the scalar one
+    i = 123456
+    h = R._mix32(0x1234 ^ R._mix32((i + 0x632BE5AB) & 0xFFFFFFFF))
+    assert R.sample_uniform_at(0x1234, i + 1)[i] == (np.float32(h >> 9) + np.float32(0.5)) * np.float32(2.0 ** -23)
+
+
+def test_full_vocabulary_draw_follows_the_softmax():
+    """top_k disabled and top_p = 1: tokens outside any 1024-candidate set are drawn with their
+    softmax probability (a nearly flat row of 4096 logits, where the tail holds most of the mass)."""
+    rng = np.random.default_rng(12)
+    V, n, T = 4096, 6000, 1.3
+    row = (rng.standard_normal(V) * 0.5).astype(np.float32)
+    row[:8] += 4.0
+    ids = R.sample_topk_topp(np.tile(row, (n, 1)), np.full(n, T, np.float32), np.full(n, -1, np.int32),
+                             np.ones(n, np.float32), np.arange(n) * 31 + 5, np.arange(n) % 97)
+    p = np.exp(row.astype(np.float64) / T)
+    p /= p.sum()
+    order = np.argsort(-row, kind="stable")
+    tail = np.zeros(V, bool)
+    tail[order[1024:]] = True
+    assert abs(tail[ids].mean() - p[tail].sum()) < 4 * np.sqrt(p[tail].sum() / n)
+    for t in range(8):
+        assert abs((ids == t).mean() - p[t]) < 4 * np.sqrt(p[t] / n) + 1e-3
+    # special rows: a NaN wins, -inf never does, an all-tied row is still a uniform draw
+    lg = np.zeros((3, 64), np.float32)
+    lg[0, 9] = np.nan
+    lg[1, :] = -np.inf
+    lg[1, 40] = -3.0
+    out = R.sample_topk_topp(lg, np.ones(3, np.float32), np.zeros(3, np.int32), np.ones(3, np.float32), [1, 2, 3], [0, 0, 0])
+    assert out[0] == 9 and out[1] == 40 and 0 <= out[2] < 64

@@ -156,7 +156,7 @@ __global__ void argmax_key_to_index_kernel(int64_t* __restrict__ out, const int6
 
 // ---------------------------------------------------------------------------
 // Random sampling: temperature, top-k (k <= 1024), top-p, one 1024-thread
-// workgroup per row.  Every arithmetic step is plain fp32 in a fixed order
+// workgroup per row.  (A row with neither cut takes sample_full_vocab below.)  Every arithmetic step is plain fp32 in a fixed order
 // (contraction off, polynomial exp, sequential cumulative sum), so the result is
 // a pure function of (logits, parameters, seed, step) and equals the CPU
 // restatement bit for bit.
@@ -202,12 +202,51 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   return x;
 }
 
-__device__ __forceinline__ float sample_uniform(uint64_t seed, uint64_t step) {
+__device__ __forceinline__ uint32_t sample_hash(uint64_t seed, uint64_t step) {
   uint32_t h = mix32(static_cast<uint32_t>(seed) ^ 0x9E3779B9u);
   h = mix32(h ^ static_cast<uint32_t>(seed >> 32));
   h = mix32(h ^ static_cast<uint32_t>(step));
-  h = mix32(h ^ static_cast<uint32_t>(step >> 32) ^ 0x85EBCA6Bu);
-  return (static_cast<float>(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  return mix32(h ^ static_cast<uint32_t>(step >> 32) ^ 0x85EBCA6Bu);
+}
+
+__device__ __forceinline__ float sample_uniform(uint64_t seed, uint64_t step) {
+  return (static_cast<float>(sample_hash(seed, step) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+// One uniform per (seed, step, token index), strictly inside (0, 1): 23 hash bits, centred, so
+// that both 2^-24 and 1 - 2^-24 are exact fp32 values and log(u), log(-log(u)) stay finite.
+__device__ __forceinline__ float sample_uniform_at(uint32_t row_hash, uint32_t index) {
+  const uint32_t h = mix32(row_hash ^ mix32(index + 0x632BE5ABu));
+  return (static_cast<float>(h >> 9) + 0.5f) * (1.0f / 8388608.0f);
+}
+
+// ln(x) for a positive normal x: x = 2^e * m with m in [sqrt(1/2), sqrt(2)), ln(m) = 2 atanh(s),
+// s = (m - 1) / (m + 1), |s| < 0.172, odd series to s^9 (next term < 1e-9).  Every operation is one
+// IEEE fp32 operation in the order written.
+__device__ __forceinline__ float ln_det(float x) {
+#pragma clang fp contract(off)
+  const uint32_t bits = __float_as_uint(x);
+  int e = static_cast<int>(bits >> 23) - 127;
+  float m = __uint_as_float((bits & 0x007FFFFFu) | 0x3F800000u);
+  if (m > 1.41421354f) {
+    m = m * 0.5f;
+    e += 1;
+  }
+  const float s = (m - 1.0f) / (m + 1.0f);
+  const float s2 = s * s;
+  float p = 0.11111111f;
+  p = p * s2;
+  p = p + 0.14285715f;
+  p = p * s2;
+  p = p + 0.2f;
+  p = p * s2;
+  p = p + 0.33333334f;
+  p = p * s2;
+  p = p + 1.0f;
+  float r = s * p;
+  r = r + r;
+  const float base = static_cast<float>(e) * 0.69314718f;
+  return base + r;
 }
 
 // exp(z), z <= 0: 2^n * poly(f) with y = z*log2(e), n = floor(y), f = y - n.
@@ -231,6 +270,39 @@ __device__ __forceinline__ float exp_det(float z) {
   return r * scale;
 }
 
+// Full-vocabulary draw for a row with neither top-k nor top-p: the Gumbel-max form of sampling
+// from softmax(logits / t),
+//     token = argmax_i ( logit_i / t  -  ln(-ln(u_i)) ),   u_i = sample_uniform_at(hash(seed, step), i),
+// one pass over the row, no candidate set.  Scores are compared through the same order-preserving
+// keys as everywhere else (a NaN logit wins, ties go to the lowest index).
+template <int LDT>
+__device__ __forceinline__ void sample_full_vocab(int64_t* __restrict__ out, const void* __restrict__ base, int row,
+                                                  int vocab, float temp, uint64_t seed, uint64_t step) {
+#pragma clang fp contract(off)
+  const uint32_t row_hash = sample_hash(seed, step);
+  unsigned long long best = 0ull;
+  for (int i = threadIdx.x; i < vocab; i += kSampleThreads) {
+    const float l = load_logit<LDT>(base, i);
+    const float u = sample_uniform_at(row_hash, static_cast<uint32_t>(i));
+    const float a = -ln_det(u);
+    const float g = ln_det(a);
+    const float scaled = l / temp;
+    const float score = scaled - g;
+    best = umax64(best, argmax_key(l != l ? l : score, static_cast<uint32_t>(i)));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) best = umax64(best, __shfl_xor(best, off, 64));
+  __shared__ unsigned long long part[kSampleThreads / 64];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long b = part[0];
+#pragma unroll
+    for (int i = 1; i < kSampleThreads / 64; ++i) b = umax64(b, part[i]);
+    MI355_ST(int64_t, out, out + row, static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(b & 0xFFFFFFFFull)));
+  }
+}
+
 template <int LDT>
 __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
     int64_t* __restrict__ out, const void* __restrict__ logits, int64_t stride, int vocab,
@@ -245,6 +317,11 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
                          ? static_cast<const void*>(static_cast<const float*>(logits) + row * stride)
                          : static_cast<const void*>(static_cast<const uint16_t*>(logits) + row * stride);
   int k = MI355_LD(int32_t, top_k, top_k + row);
+  if (k <= 0 && !(MI355_LD(float, top_p, top_p + row) < 1.0f)) {   // nothing to cut: draw from the whole row
+    sample_full_vocab<LDT>(out, base, row, vocab, temp, static_cast<uint64_t>(MI355_LD(int64_t, seeds, seeds + row)),
+                           static_cast<uint64_t>(MI355_LD(int64_t, steps, steps + row)));
+    return;
+  }
   k = (k > 0 && k <= kSampleKMax) ? k : kSampleKMax;
   k = min(k, vocab);
 
