@@ -156,21 +156,31 @@ __global__ void argmax_key_to_index_kernel(int64_t* __restrict__ out, const int6
 
 // ---------------------------------------------------------------------------
 // Random sampling: temperature, top-k (k <= 1024), top-p, one 1024-thread
-// workgroup per row.  (A row with neither cut takes sample_full_vocab below.)  Every arithmetic step is plain fp32 in a fixed order
-// (contraction off, polynomial exp, sequential cumulative sum), so the result is
-// a pure function of (logits, parameters, seed, step) and equals the CPU
-// restatement bit for bit.
-//   1. radix select (4 passes of 8 bits over order-preserving keys, LDS
-//      histogram) finds the k-th largest key T
-//   2. candidates = keys > T, plus the lowest-index keys == T (ordered placement
-//      with wave ballots over wave-contiguous ranges)
-//   3. bitonic sort in LDS by (key desc, index asc)
-//   4. w_i = exp((l_i - l_0) / t); sequential cumulative sum; top-p cut; one
-//      uniform from a counter hash of (seed, step) picks the token by inverse CDF
-// The row (vocab * 2 or 4 bytes) is read 6 times, L2-resident after the first.
+// workgroup per row.  Every arithmetic step is plain fp32 in a fixed order
+// (contraction off, polynomial exp and ln, sequential cumulative sum), so the
+// result is a pure function of (logits, parameters, seed, step) and equals the
+// CPU restatement bit for bit.  Three kinds of row:
+//   temperature <= 0      the greedy token (one pass, the argmax key)
+//   no cut (top_k <= 0 and top_p >= 1)
+//                         Gumbel-max over the whole row (one pass)
+//   a cut                 the k best (logit desc, index asc), k <= 1024:
+//     1. one pass keeps every thread's two largest keys; the k-th largest of those
+//        2048 (bitonic sort in LDS) is a threshold t that at least k logits reach,
+//        and for logits without a pathological layout only a few more than k do
+//     2. a second pass appends every logit >= t to an LDS list (<= 4096 entries)
+//        and a bitonic sort of the list puts the k best in front, in order.
+//        A list that overflows (huge ties, adversarial layouts) takes the exact
+//        4-pass radix select instead (LDS histogram of 8 key bits a pass, ordered
+//        placement of the ties at the threshold, sort of the 1024)
+//     3. w_i = exp((l_i - l_0) / t); sequential cumulative sum by one lane; top-p
+//        cut; one uniform from a counter hash of (seed, step) picks the token by
+//        inverse CDF
+// The streaming passes read the row (vocab * 2 or 4 bytes, L2-resident after the
+// first) with 16-byte loads and touch LDS only for the few survivors.
 // ---------------------------------------------------------------------------
 constexpr int kSampleThreads = 1024;
 constexpr int kSampleKMax = 1024;
+constexpr int kSampleCap = 4096;     // candidates at or above the threshold guess that LDS holds
 
 // NaN sorts on top, as in argmax_key: a row that holds a NaN yields the index of its first NaN
 // from greedy and from random sampling alike
@@ -270,77 +280,99 @@ __device__ __forceinline__ float exp_det(float z) {
   return r * scale;
 }
 
-// Full-vocabulary draw for a row with neither top-k nor top-p: the Gumbel-max form of sampling
+// fn(logit, index) for every logit of the row, 16 bytes per lane per load.
+template <int LDT, int UNROLL = 2, typename F>
+__device__ __forceinline__ void for_each_logit(const void* base, int vocab, F&& fn) {
+  constexpr int PER = LDT == MI355_F32 ? 4 : 8;
+  const int nvec = vocab / PER;
+#pragma unroll UNROLL
+  for (int v = threadIdx.x; v < nvec; v += kSampleThreads) {
+    float f[8];
+    if (LDT == MI355_F32) {
+      const float4 q = MI355_LD(float4, base, static_cast<const float*>(base) + 4 * v);
+      f[0] = q.x, f[1] = q.y, f[2] = q.z, f[3] = q.w;
+    } else {
+      const uint4 raw = MI355_LD(uint4, base, static_cast<const uint16_t*>(base) + 8 * v);
+      if (LDT == MI355_BF16) unpack8<BF16>(raw, f); else unpack8<F16>(raw, f);
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) fn(f[j], v * PER + j);
+  }
+  for (int i = nvec * PER + threadIdx.x; i < vocab; i += kSampleThreads) fn(load_logit<LDT>(base, i), i);
+}
+
+// Workgroup-wide max of the 64-bit keys; thread 0 gets the result.
+__device__ __forceinline__ unsigned long long sample_reduce_max(unsigned long long best, unsigned long long* part) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) best = umax64(best, __shfl_xor(best, off, 64));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int i = 1; i < kSampleThreads / 64; ++i) best = umax64(best, part[i]);
+  return best;
+}
+
+// In-place descending bitonic sort of a[0, P), P a power of two, by the whole workgroup.  The
+// caller has made a[] visible (a barrier) before the call; a[] is visible to all after it.
+template <typename T>
+__device__ __forceinline__ void bitonic_desc(T* a, int P) {
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int j = size >> 1; j > 0; j >>= 1) {
+      for (int idx = threadIdx.x; idx < (P >> 1); idx += kSampleThreads) {
+        const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+        const int p = i | j;
+        const T x = a[i], y = a[p];
+        const bool desc = (i & size) == 0;
+        if (desc ? (x < y) : (x > y)) {
+          a[i] = y;
+          a[p] = x;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Whole-vocabulary draw for a row with neither top-k nor top-p: the Gumbel-max form of sampling
 // from softmax(logits / t),
 //     token = argmax_i ( logit_i / t  -  ln(-ln(u_i)) ),   u_i = sample_uniform_at(hash(seed, step), i),
 // one pass over the row, no candidate set.  Scores are compared through the same order-preserving
 // keys as everywhere else (a NaN logit wins, ties go to the lowest index).
 template <int LDT>
-__device__ __forceinline__ void sample_full_vocab(int64_t* __restrict__ out, const void* __restrict__ base, int row,
-                                                  int vocab, float temp, uint64_t seed, uint64_t step) {
+__device__ __forceinline__ unsigned long long sample_full_vocab(const void* __restrict__ base, int vocab, float temp,
+                                                                uint64_t seed, uint64_t step) {
 #pragma clang fp contract(off)
   const uint32_t row_hash = sample_hash(seed, step);
   unsigned long long best = 0ull;
-  for (int i = threadIdx.x; i < vocab; i += kSampleThreads) {
-    const float l = load_logit<LDT>(base, i);
+  for_each_logit<LDT>(base, vocab, [&](float l, int i) {
     const float u = sample_uniform_at(row_hash, static_cast<uint32_t>(i));
     const float a = -ln_det(u);
     const float g = ln_det(a);
     const float scaled = l / temp;
     const float score = scaled - g;
     best = umax64(best, argmax_key(l != l ? l : score, static_cast<uint32_t>(i)));
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) best = umax64(best, __shfl_xor(best, off, 64));
-  __shared__ unsigned long long part[kSampleThreads / 64];
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = best;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long b = part[0];
-#pragma unroll
-    for (int i = 1; i < kSampleThreads / 64; ++i) b = umax64(b, part[i]);
-    MI355_ST(int64_t, out, out + row, static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(b & 0xFFFFFFFFull)));
-  }
+  });
+  return best;
 }
 
+// The exact top-k by radix select straight from the row, for rows whose candidate list does not
+// fit LDS: leaves the k best composites, sorted, in comp[0, k).  `need` keys equal to the k-th
+// largest key T are taken, lowest indices first (ordered placement with wave ballots over
+// wave-contiguous index ranges).
 template <int LDT>
-__global__ __launch_bounds__(kSampleThreads) void sample_kernel(
-    int64_t* __restrict__ out, const void* __restrict__ logits, int64_t stride, int vocab,
-    const float* __restrict__ temperature, const int32_t* __restrict__ top_k, const float* __restrict__ top_p,
-    const int64_t* __restrict__ seeds, const int64_t* __restrict__ steps) {
-#pragma clang fp contract(off)
-  const int row = blockIdx.x;
-  const float temp = MI355_LD(float, temperature, temperature + row);
-  if (!(temp > 0.0f)) return;  // greedy rows keep the argmax written before
+__device__ __forceinline__ void select_by_radix(const void* base, int vocab, int k, unsigned long long* comp,
+                                                int* hist, int* eq_base, int* sh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const void* base = LDT == MI355_F32
-                         ? static_cast<const void*>(static_cast<const float*>(logits) + row * stride)
-                         : static_cast<const void*>(static_cast<const uint16_t*>(logits) + row * stride);
-  int k = MI355_LD(int32_t, top_k, top_k + row);
-  if (k <= 0 && !(MI355_LD(float, top_p, top_p + row) < 1.0f)) {   // nothing to cut: draw from the whole row
-    sample_full_vocab<LDT>(out, base, row, vocab, temp, static_cast<uint64_t>(MI355_LD(int64_t, seeds, seeds + row)),
-                           static_cast<uint64_t>(MI355_LD(int64_t, steps, steps + row)));
-    return;
-  }
-  k = (k > 0 && k <= kSampleKMax) ? k : kSampleKMax;
-  k = min(k, vocab);
-
-  __shared__ int hist[256];
-  __shared__ unsigned long long comp[kSampleKMax];
-  __shared__ float csum[kSampleKMax];
-  __shared__ int sh_digit, sh_need, sh_gt;
-  __shared__ int eq_base[kSampleThreads / 64 + 1];
-
-  // ---- 1. radix select of the k-th largest key
   uint32_t prefix = 0u, mask = 0u;
   int need = k;
   for (int shift = 24; shift >= 0; shift -= 8) {
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < vocab; i += kSampleThreads) {
-      const uint32_t key = sample_key(load_logit<LDT>(base, i));
+    for_each_logit<LDT>(base, vocab, [&](float f, int) {
+      const uint32_t key = sample_key(f);
       if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
-    }
+    });
     __syncthreads();
     if (tid == 0) {
       int rem = need, d = 255;
@@ -348,19 +380,18 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
         if (hist[d] >= rem) break;
         rem -= hist[d];
       }
-      sh_digit = d;
-      sh_need = rem;
+      sh[0] = d;
+      sh[1] = rem;
     }
     __syncthreads();
-    prefix |= static_cast<uint32_t>(sh_digit) << shift;
+    prefix |= static_cast<uint32_t>(sh[0]) << shift;
     mask |= 255u << shift;
-    need = sh_need;
+    need = sh[1];
     __syncthreads();
   }
-  const uint32_t T = prefix;  // `need` keys equal to T are taken, lowest indices first
+  const uint32_t T = prefix;
   const int n_gt = k - need;
 
-  // ---- 2. gather: wave w owns the contiguous index range [w*R, (w+1)*R)
   const int R = ((vocab + (kSampleThreads / 64) - 1) / (kSampleThreads / 64) + 63) / 64 * 64;
   const int r0 = wave * R, r1 = min(vocab, r0 + R);
   int eq_count = 0;
@@ -369,7 +400,7 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
     const bool eq = i < r1 && sample_key(load_logit<LDT>(base, i)) == T;
     eq_count += __popcll(__ballot(eq));
   }
-  if (tid == 0) sh_gt = 0;
+  if (tid == 0) sh[2] = 0;
   for (int i = tid; i < kSampleKMax; i += kSampleThreads) comp[i] = 0ull;
   if (lane == 0) eq_base[wave + 1] = eq_count;
   __syncthreads();
@@ -391,7 +422,7 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
     const unsigned long long eqm = __ballot(eq);
     const unsigned long long cv = (static_cast<unsigned long long>(key) << 32) |
                                   static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<uint32_t>(i));
-    if (gt) comp[atomicAdd(&sh_gt, 1)] = cv;
+    if (gt) comp[atomicAdd(&sh[2], 1)] = cv;
     if (eq) {
       const int rank = eq_run + __popcll(eqm & ((1ull << lane) - 1ull));
       if (rank < need) comp[n_gt + rank] = cv;
@@ -399,59 +430,144 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
     eq_run += __popcll(eqm);
   }
   __syncthreads();
+  bitonic_desc(comp, kSampleKMax);
+}
 
-  // ---- 3. bitonic sort, descending
-  for (int size = 2; size <= kSampleKMax; size <<= 1) {
-    for (int j = size >> 1; j > 0; j >>= 1) {
-      const int p = tid ^ j;
-      if (p > tid) {
-        const unsigned long long a = comp[tid], b = comp[p];
-        const bool desc = (tid & size) == 0;
-        if (desc ? (a < b) : (a > b)) {
-          comp[tid] = b;
-          comp[p] = a;
-        }
-      }
-      __syncthreads();
+template <int LDT>
+__global__ __launch_bounds__(kSampleThreads) void sample_kernel(
+    int64_t* __restrict__ out, const void* __restrict__ logits, int64_t stride, int vocab,
+    const float* __restrict__ temperature, const int32_t* __restrict__ top_k, const float* __restrict__ top_p,
+    const int64_t* __restrict__ seeds, const int64_t* __restrict__ steps) {
+#pragma clang fp contract(off)
+  const int row = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const void* base = LDT == MI355_F32
+                         ? static_cast<const void*>(static_cast<const float*>(logits) + row * stride)
+                         : static_cast<const void*>(static_cast<const uint16_t*>(logits) + row * stride);
+  __shared__ unsigned long long comp[kSampleCap];
+  __shared__ uint32_t skeys[2 * kSampleThreads];
+  __shared__ __align__(16) float csum[kSampleKMax];
+  __shared__ unsigned long long part[kSampleThreads / 64];
+  __shared__ int hist[256];
+  __shared__ int eq_base[kSampleThreads / 64 + 1];
+  __shared__ int sh[4];
+
+  const float temp = MI355_LD(float, temperature, temperature + row);
+  int k = MI355_LD(int32_t, top_k, top_k + row);
+  const float tp = MI355_LD(float, top_p, top_p + row);
+  const uint64_t seed = static_cast<uint64_t>(MI355_LD(int64_t, seeds, seeds + row));
+  const uint64_t step = static_cast<uint64_t>(MI355_LD(int64_t, steps, steps + row));
+  const bool greedy = !(temp > 0.0f);
+  if (greedy || (k <= 0 && !(tp < 1.0f))) {            // one pass, one key
+    unsigned long long best = 0ull;
+    if (greedy)
+      for_each_logit<LDT>(base, vocab, [&](float f, int i) { best = umax64(best, argmax_key(f, static_cast<uint32_t>(i))); });
+    else
+      best = sample_full_vocab<LDT>(base, vocab, temp, seed, step);
+    best = sample_reduce_max(best, part);
+    if (tid == 0)
+      MI355_ST(int64_t, out, out + row, static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(best & 0xFFFFFFFFull)));
+    return;
+  }
+  k = (k > 0 && k <= kSampleKMax) ? k : kSampleKMax;
+  k = min(k, vocab);
+
+  // ---- 1. threshold guess: the k-th largest of every thread's two largest keys.  Those 2048
+  // keys are keys of distinct logits of the row and at least min(vocab, 2048) >= k of them are
+  // real (> 0), so at least k logits of the row reach the guess.
+  uint32_t m1 = 0u, m2 = 0u;
+  for_each_logit<LDT>(base, vocab, [&](float f, int) {
+    const uint32_t key = sample_key(f);
+    m2 = max(m2, min(m1, key));
+    m1 = max(m1, key);
+  });
+  skeys[2 * tid] = m1;
+  skeys[2 * tid + 1] = m2;
+  if (tid == 0) sh[3] = 0;
+  __syncthreads();
+  bitonic_desc(skeys, 2 * kSampleThreads);
+  const uint32_t guess = skeys[k - 1];
+
+  // ---- 2. every logit at or above the guess, appended to the list one wave at a time
+  for_each_logit<LDT, 1>(base, vocab, [&](float f, int i) {
+    const uint32_t key = sample_key(f);
+    const bool take = key >= guess;
+    const unsigned long long m = __ballot(take);
+    if (m != 0ull) {
+      const int leader = __ffsll(static_cast<long long>(m)) - 1;
+      int pos = 0;
+      if (lane == leader) pos = atomicAdd(&sh[3], __popcll(m));
+      pos = __shfl(pos, leader, 64) + __popcll(m & ((1ull << lane) - 1ull));
+      if (take && pos < kSampleCap)
+        comp[pos] = (static_cast<unsigned long long>(key) << 32) |
+                    static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<uint32_t>(i));
     }
+  });
+  __syncthreads();
+  const int n = sh[3];
+  if (n <= kSampleCap) {
+    int P = 64;
+    while (P < n) P <<= 1;
+    for (int i = n + tid; i < P; i += kSampleThreads) comp[i] = 0ull;
+    __syncthreads();
+    bitonic_desc(comp, P);
+  } else {
+    select_by_radix<LDT>(base, vocab, k, comp, hist, eq_base, sh);
   }
 
-  // ---- 4. weights, sequential cumulative sum, top-p cut, inverse-CDF pick
-  const float l0 = key_to_logit(static_cast<uint32_t>(comp[0] >> 32));
+  // ---- 3. weights, sequential cumulative sum, top-p cut, inverse-CDF pick
+  const uint32_t key0 = static_cast<uint32_t>(comp[0] >> 32);
+  if (key0 == 0xFFFFFFFFu) {                            // a NaN logit: its index, like argmax
+    if (tid == 0)
+      MI355_ST(int64_t, out, out + row, static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(comp[0] & 0xFFFFFFFFull)));
+    return;
+  }
+  const float l0 = key_to_logit(key0);
   if (tid < k) {
     const float li = key_to_logit(static_cast<uint32_t>(comp[tid] >> 32));
     float z = (li - l0) / temp;
     if (z != z) z = -INFINITY;
     csum[tid] = exp_det(z);
   }
+  if (tid == 0) {
+    sh[0] = k;             // keep
+    sh[1] = kSampleKMax;   // pick
+  }
   __syncthreads();
-  if (tid == 0 && static_cast<uint32_t>(comp[0] >> 32) == 0xFFFFFFFFu) {   // a NaN logit: its index, like argmax
-    MI355_ST(int64_t, out, out + row, static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(comp[0] & 0xFFFFFFFFull)));
-  } else if (tid == 0) {
+  if (tid == 0) {
     float acc = 0.0f;
-    for (int i = 0; i < k; ++i) {
+    float4* c4 = reinterpret_cast<float4*>(csum);
+    const int k4 = k >> 2;
+#pragma unroll 4
+    for (int i = 0; i < k4; ++i) {
+      float4 w = c4[i];
+      acc = acc + w.x;
+      w.x = acc;
+      acc = acc + w.y;
+      w.y = acc;
+      acc = acc + w.z;
+      w.z = acc;
+      acc = acc + w.w;
+      w.w = acc;
+      c4[i] = w;
+    }
+    for (int i = k4 << 2; i < k; ++i) {
       acc = acc + csum[i];
       csum[i] = acc;
     }
-    int keep = k;
-    const float tp = MI355_LD(float, top_p, top_p + row);
-    if (tp < 1.0f) {
-      const float thr = tp * csum[k - 1];
-      for (int i = 0; i < k; ++i)
-        if (csum[i] >= thr) {
-          keep = i + 1;
-          break;
-        }
-    }
-    const float target = sample_uniform(static_cast<uint64_t>(MI355_LD(int64_t, seeds, seeds + row)),
-                                        static_cast<uint64_t>(MI355_LD(int64_t, steps, steps + row))) *
-                         csum[keep - 1];
-    int pick = keep - 1;
-    for (int i = 0; i < keep; ++i)
-      if (csum[i] > target) {
-        pick = i;
-        break;
-      }
+  }
+  __syncthreads();
+  if (tp < 1.0f) {
+    const float thr = tp * csum[k - 1];
+    if (tid < k && csum[tid] >= thr) atomicMin(&sh[0], tid + 1);
+    __syncthreads();
+  }
+  const int keep = sh[0];
+  const float target = sample_uniform(seed, step) * csum[keep - 1];
+  if (tid < keep && csum[tid] > target) atomicMin(&sh[1], tid);
+  __syncthreads();
+  if (tid == 0) {
+    const int pick = min(sh[1], keep - 1);
     MI355_ST(int64_t, out, out + row, static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(comp[pick] & 0xFFFFFFFFull)));
   }
 }
@@ -459,9 +575,8 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
 }  // namespace mi355
 
 namespace mi355 {
-static int32_t argmax_entry(const char* name, int64_t* out, const void* logits, int64_t logits_stride,
-                            int32_t num_rows, int32_t vocab, int32_t logits_dtype, bool keyed, int64_t index_offset,
-                            void* stream) {
+static int32_t check_logits(const char* name, const int64_t* out, const void* logits, int64_t logits_stride,
+                            int32_t num_rows, int32_t vocab, int32_t logits_dtype, int64_t index_offset) {
   MI355_REQUIRE(out && logits, MI355_ERR_INVALID, "%s: null pointer", name);
   MI355_REQUIRE(num_rows >= 0 && vocab > 0, MI355_ERR_INVALID, "%s: num_rows/vocab out of range", name);
   MI355_REQUIRE(index_offset >= 0 && index_offset + vocab <= 0xFFFFFFFFll, MI355_ERR_INVALID,
@@ -472,7 +587,14 @@ static int32_t argmax_entry(const char* name, int64_t* out, const void* logits, 
   MI355_REQUIRE(logits_stride >= vocab && logits_stride % per16 == 0 && aligned16(logits),
                 MI355_ERR_INVALID, "%s: logits rows must be 16-byte aligned (stride %lld)", name,
                 (long long)logits_stride);
-  if (num_rows == 0) return MI355_OK;
+  return MI355_OK;
+}
+
+static int32_t argmax_entry(const char* name, int64_t* out, const void* logits, int64_t logits_stride,
+                            int32_t num_rows, int32_t vocab, int32_t logits_dtype, bool keyed, int64_t index_offset,
+                            void* stream) {
+  const int32_t ok = check_logits(name, out, logits, logits_stride, num_rows, vocab, logits_dtype, index_offset);
+  if (ok != MI355_OK || num_rows == 0) return ok;
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(num_rows), block(kArgmaxThreads);
   const uint32_t off = static_cast<uint32_t>(index_offset);
@@ -558,8 +680,7 @@ extern "C" int32_t mi355_sample_topk_topp(int64_t* out_ids, const void* logits, 
   using namespace mi355;
   const char* name = "mi355_sample_topk_topp";
   MI355_REQUIRE(temperature && top_k && top_p && seeds && steps, MI355_ERR_INVALID, "%s: null pointer", name);
-  // greedy token for every row first; rows with temperature > 0 are then re-drawn
-  const int32_t rc = mi355_argmax(out_ids, logits, logits_stride, num_rows, vocab, logits_dtype, stream);
+  const int32_t rc = check_logits(name, out_ids, logits, logits_stride, num_rows, vocab, logits_dtype, 0);
   if (rc != MI355_OK || num_rows == 0) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(num_rows), block(kSampleThreads);
