@@ -281,12 +281,22 @@ __device__ __forceinline__ float exp_det(float z) {
 }
 
 // fn(logit, index) for every logit of the row, 16 bytes per lane per load.
+template <int LDT, int UNROLL, typename F>
+__device__ __forceinline__ void for_each_logit_in(const void* base, int vocab, int v0, int v1, bool tail, F&& fn);
+
 template <int LDT, int UNROLL = 2, typename F>
 __device__ __forceinline__ void for_each_logit(const void* base, int vocab, F&& fn) {
+  for_each_logit_in<LDT, UNROLL>(base, vocab, 0, vocab, true, fn);
+}
+
+// The same over the 16-byte vectors [v0, v1) of the row, plus, if `tail`, the elements after the
+// last whole vector.
+template <int LDT, int UNROLL, typename F>
+__device__ __forceinline__ void for_each_logit_in(const void* base, int vocab, int v0, int v1, bool tail, F&& fn) {
   constexpr int PER = LDT == MI355_F32 ? 4 : 8;
-  const int nvec = vocab / PER;
+  const int nvec = min(v1, vocab / PER);
 #pragma unroll UNROLL
-  for (int v = threadIdx.x; v < nvec; v += kSampleThreads) {
+  for (int v = v0 + threadIdx.x; v < nvec; v += kSampleThreads) {
     float f[8];
     if (LDT == MI355_F32) {
       const float4 q = MI355_LD(float4, base, static_cast<const float*>(base) + 4 * v);
@@ -298,7 +308,8 @@ __device__ __forceinline__ void for_each_logit(const void* base, int vocab, F&& 
 #pragma unroll
     for (int j = 0; j < PER; ++j) fn(f[j], v * PER + j);
   }
-  for (int i = nvec * PER + threadIdx.x; i < vocab; i += kSampleThreads) fn(load_logit<LDT>(base, i), i);
+  if (tail)
+    for (int i = vocab / PER * PER + threadIdx.x; i < vocab; i += kSampleThreads) fn(load_logit<LDT>(base, i), i);
 }
 
 // Workgroup-wide max of the 64-bit keys; thread 0 gets the result.
@@ -340,12 +351,12 @@ __device__ __forceinline__ void bitonic_desc(T* a, int P) {
 // one pass over the row, no candidate set.  Scores are compared through the same order-preserving
 // keys as everywhere else (a NaN logit wins, ties go to the lowest index).
 template <int LDT>
-__device__ __forceinline__ unsigned long long sample_full_vocab(const void* __restrict__ base, int vocab, float temp,
-                                                                uint64_t seed, uint64_t step) {
+__device__ __forceinline__ unsigned long long sample_full_vocab(const void* __restrict__ base, int vocab, int v0, int v1,
+                                                                bool tail, float temp, uint64_t seed, uint64_t step) {
 #pragma clang fp contract(off)
   const uint32_t row_hash = sample_hash(seed, step);
   unsigned long long best = 0ull;
-  for_each_logit<LDT>(base, vocab, [&](float l, int i) {
+  for_each_logit_in<LDT, 2>(base, vocab, v0, v1, tail, [&](float l, int i) {
     const float u = sample_uniform_at(row_hash, static_cast<uint32_t>(i));
     const float a = -ln_det(u);
     const float g = ln_det(a);
@@ -433,11 +444,27 @@ __device__ __forceinline__ void select_by_radix(const void* base, int vocab, int
   bitonic_desc(comp, kSampleKMax);
 }
 
+// Rows that need one key only: greedy ones and draws with neither top-k nor top-p.
+__device__ __forceinline__ bool sample_one_key(float temp, int top_k, float top_p) {
+  return !(temp > 0.0f) || (top_k <= 0 && !(top_p < 1.0f));
+}
+
+__global__ void sample_finish_kernel(int64_t* __restrict__ out, const float* __restrict__ temperature,
+                                     const int32_t* __restrict__ top_k, const float* __restrict__ top_p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (!sample_one_key(MI355_LD(float, temperature, temperature + i), MI355_LD(int32_t, top_k, top_k + i),
+                      MI355_LD(float, top_p, top_p + i)))
+    return;
+  const unsigned long long b = static_cast<unsigned long long>(MI355_LD(int64_t, out, out + i));
+  MI355_ST(int64_t, out, out + i, static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(b & 0xFFFFFFFFull)));
+}
+
 template <int LDT>
 __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
     int64_t* __restrict__ out, const void* __restrict__ logits, int64_t stride, int vocab,
     const float* __restrict__ temperature, const int32_t* __restrict__ top_k, const float* __restrict__ top_p,
-    const int64_t* __restrict__ seeds, const int64_t* __restrict__ steps) {
+    const int64_t* __restrict__ seeds, const int64_t* __restrict__ steps, int chunk_vecs) {
 #pragma clang fp contract(off)
   const int row = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -458,17 +485,24 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
   const uint64_t seed = static_cast<uint64_t>(MI355_LD(int64_t, seeds, seeds + row));
   const uint64_t step = static_cast<uint64_t>(MI355_LD(int64_t, steps, steps + row));
   const bool greedy = !(temp > 0.0f);
-  if (greedy || (k <= 0 && !(tp < 1.0f))) {            // one pass, one key
+  if (sample_one_key(temp, k, tp)) {
+    // one pass, one key: the row is cut into gridDim.y column ranges, every workgroup merges the
+    // best key of its range into out[row] (cleared by the launcher) with a 64-bit atomic max --
+    // order-free, so the same on every launch -- and sample_finish_kernel turns it into the index
+    const int v0 = blockIdx.y * chunk_vecs, v1 = v0 + chunk_vecs;
+    const bool tail = blockIdx.y == gridDim.y - 1;
     unsigned long long best = 0ull;
     if (greedy)
-      for_each_logit<LDT>(base, vocab, [&](float f, int i) { best = umax64(best, argmax_key(f, static_cast<uint32_t>(i))); });
+      for_each_logit_in<LDT, 2>(base, vocab, v0, v1, tail,
+                                [&](float f, int i) { best = umax64(best, argmax_key(f, static_cast<uint32_t>(i))); });
     else
-      best = sample_full_vocab<LDT>(base, vocab, temp, seed, step);
+      best = sample_full_vocab<LDT>(base, vocab, v0, v1, tail, temp, seed, step);
     best = sample_reduce_max(best, part);
-    if (tid == 0)
-      MI355_ST(int64_t, out, out + row, static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(best & 0xFFFFFFFFull)));
+    if (tid == 0 && best != 0ull && MI355_OK_AT(out, out + row, 8))
+      atomicMax(reinterpret_cast<unsigned long long*>(out) + row, best);
     return;
   }
+  if (blockIdx.y != 0) return;
   k = (k > 0 && k <= kSampleKMax) ? k : kSampleKMax;
   k = min(k, vocab);
 
@@ -683,15 +717,28 @@ extern "C" int32_t mi355_sample_topk_topp(int64_t* out_ids, const void* logits, 
   const int32_t rc = check_logits(name, out_ids, logits, logits_stride, num_rows, vocab, logits_dtype, 0);
   if (rc != MI355_OK || num_rows == 0) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  dim3 grid(num_rows), block(kSampleThreads);
+  // one-key rows (greedy, no cut) are spread over `chunks` workgroups each so that few rows still
+  // occupy every CU: their pass is ALU-bound (two logarithms and two divisions per logit)
+  const int nvec = vocab / (logits_dtype == MI355_F32 ? 4 : 8);
+  int chunks = (512 + num_rows - 1) / num_rows;
+  chunks = chunks < 1 ? 1 : chunks > 64 ? 64 : chunks;
+  while (chunks > 1 && (nvec + chunks - 1) / chunks < kSampleThreads) --chunks;
+  const int chunk_vecs = (nvec + chunks - 1) / chunks;
+  const hipError_t cleared = hipMemsetAsync(out_ids, 0, sizeof(int64_t) * num_rows, s);
+  MI355_REQUIRE(cleared == hipSuccess, MI355_ERR_LAUNCH, "%s: clearing the keys failed: %s", name, hipGetErrorString(cleared));
+  dim3 grid(num_rows, chunks), block(kSampleThreads);
   if (logits_dtype == MI355_F32)
     hipLaunchKernelGGL((sample_kernel<MI355_F32>), grid, block, 0, s, out_ids, logits, logits_stride, vocab,
-                       temperature, top_k, top_p, seeds, steps);
+                       temperature, top_k, top_p, seeds, steps, chunk_vecs);
   else if (logits_dtype == MI355_BF16)
     hipLaunchKernelGGL((sample_kernel<MI355_BF16>), grid, block, 0, s, out_ids, logits, logits_stride, vocab,
-                       temperature, top_k, top_p, seeds, steps);
+                       temperature, top_k, top_p, seeds, steps, chunk_vecs);
   else
     hipLaunchKernelGGL((sample_kernel<MI355_F16>), grid, block, 0, s, out_ids, logits, logits_stride, vocab,
-                       temperature, top_k, top_p, seeds, steps);
+                       temperature, top_k, top_p, seeds, steps, chunk_vecs);
+  const int32_t rc2 = check_launch(name);
+  if (rc2 != MI355_OK) return rc2;
+  hipLaunchKernelGGL(sample_finish_kernel, dim3((num_rows + 255) / 256), dim3(256), 0, s, out_ids, temperature, top_k,
+                     top_p, num_rows);
   return check_launch(name);
 }
