@@ -164,17 +164,18 @@ __global__ void argmax_key_to_index_kernel(int64_t* __restrict__ out, const int6
 //   no cut (top_k <= 0 and top_p >= 1)
 //                         Gumbel-max over the whole row (one pass)
 //   a cut                 the k best (logit desc, index asc), k <= 1024:
-//     1. one pass keeps every thread's two largest keys; the k-th largest of those
-//        2048 (bitonic sort in LDS) is a threshold t that at least k logits reach,
-//        and for logits without a pathological layout only a few more than k do
+//     1. one pass keeps every thread's two largest keys (registers); two 8-bit radix
+//        passes over those 2048 keys (LDS histogram) give the upper 16 bits of their
+//        k-th largest: a threshold t that at least k logits reach and, for logits
+//        without a pathological layout, only a few more than k do
 //     2. a second pass appends every logit >= t to an LDS list (<= 4096 entries)
 //        and a bitonic sort of the list puts the k best in front, in order.
 //        A list that overflows (huge ties, adversarial layouts) takes the exact
 //        4-pass radix select instead (LDS histogram of 8 key bits a pass, ordered
 //        placement of the ties at the threshold, sort of the 1024)
-//     3. w_i = exp((l_i - l_0) / t); sequential cumulative sum by one lane; top-p
-//        cut; one uniform from a counter hash of (seed, step) picks the token by
-//        inverse CDF
+//     3. w_i = exp((l_i - l_0) / t); cumulative sum in a fixed blocked order (64
+//        blocks of 16) by one wave; top-p cut; one uniform from a counter hash of
+//        (seed, step) picks the token by inverse CDF
 // The streaming passes read the row (vocab * 2 or 4 bytes, L2-resident after the
 // first) with 16-byte loads and touch LDS only for the few survivors.
 // ---------------------------------------------------------------------------
@@ -312,6 +313,31 @@ __device__ __forceinline__ void for_each_logit_in(const void* base, int vocab, i
     for (int i = vocab / PER * PER + threadIdx.x; i < vocab; i += kSampleThreads) fn(load_logit<LDT>(base, i), i);
 }
 
+// fn(f, n, i0) for every 16-byte vector of the row (n = 4 or 8 logits f[0, n) starting at index
+// i0) and, one by one (n = 1), for the elements after the last whole vector.
+template <int LDT, int UNROLL, typename F>
+__device__ __forceinline__ void for_each_vector(const void* base, int vocab, F&& fn) {
+  constexpr int PER = LDT == MI355_F32 ? 4 : 8;
+  const int nvec = vocab / PER;
+#pragma unroll UNROLL
+  for (int v = threadIdx.x; v < nvec; v += kSampleThreads) {
+    float f[8];
+    if (LDT == MI355_F32) {
+      const float4 q = MI355_LD(float4, base, static_cast<const float*>(base) + 4 * v);
+      f[0] = q.x, f[1] = q.y, f[2] = q.z, f[3] = q.w;
+      f[4] = f[5] = f[6] = f[7] = 0.f;
+    } else {
+      const uint4 raw = MI355_LD(uint4, base, static_cast<const uint16_t*>(base) + 8 * v);
+      if (LDT == MI355_BF16) unpack8<BF16>(raw, f); else unpack8<F16>(raw, f);
+    }
+    fn(f, PER, v * PER);
+  }
+  for (int i = nvec * PER + threadIdx.x; i < vocab; i += kSampleThreads) {
+    float f[8] = {load_logit<LDT>(base, i), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    fn(f, 1, i);
+  }
+}
+
 // Workgroup-wide max of the 64-bit keys; thread 0 gets the result.
 __device__ __forceinline__ unsigned long long sample_reduce_max(unsigned long long best, unsigned long long* part) {
 #pragma unroll
@@ -326,22 +352,83 @@ __device__ __forceinline__ unsigned long long sample_reduce_max(unsigned long lo
 
 // In-place descending bitonic sort of a[0, P), P a power of two, by the whole workgroup.  The
 // caller has made a[] visible (a barrier) before the call; a[] is visible to all after it.
+// The array is cut into chunks of C >= 128 elements, one per wave: a compare-exchange step whose
+// partner distance j is below C stays inside the chunks and needs no workgroup barrier (a wave's
+// LDS operations execute in order), so of the 66 steps of a 2048-element sort only 10 end in one.
 template <typename T>
 __device__ __forceinline__ void bitonic_desc(T* a, int P) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = P >= 128 * (kSampleThreads / 64) ? P / (kSampleThreads / 64) : min(P, 128);
+  const bool mine = wave * C < P;
+  T* chunk = a + wave * C;
+  bool local_dirty = false;
   for (int size = 2; size <= P; size <<= 1) {
     for (int j = size >> 1; j > 0; j >>= 1) {
-      for (int idx = threadIdx.x; idx < (P >> 1); idx += kSampleThreads) {
-        const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
-        const int p = i | j;
-        const T x = a[i], y = a[p];
-        const bool desc = (i & size) == 0;
-        if (desc ? (x < y) : (x > y)) {
-          a[i] = y;
-          a[p] = x;
+      if (j < C) {
+        if (mine) {
+          for (int q = lane; q < (C >> 1); q += 64) {
+            const int il = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+            const T x = chunk[il], y = chunk[il | j];
+            const bool desc = ((wave * C + il) & size) == 0;
+            if (desc ? (x < y) : (x > y)) {
+              chunk[il] = y;
+              chunk[il | j] = x;
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        local_dirty = true;
+      } else {
+        if (local_dirty) __syncthreads();
+        local_dirty = false;
+        for (int idx = threadIdx.x; idx < (P >> 1); idx += kSampleThreads) {
+          const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+          const int p = i | j;
+          const T x = a[i], y = a[p];
+          const bool desc = (i & size) == 0;
+          if (desc ? (x < y) : (x > y)) {
+            a[i] = y;
+            a[p] = x;
+          }
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
+  }
+  __syncthreads();
+}
+
+// By wave 0: the largest digit d of a 256-bin histogram with at least `need` entries in bins
+// >= d, and how many of them bin d itself has to supply.  Lane l owns bins 4l .. 4l+3.
+__device__ __forceinline__ void radix_pick(const int* hist, int need, int* digit, int* rem) {
+  const int lane = threadIdx.x & 63;
+  int h4[4], s = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h4[j] = hist[4 * lane + j];
+    s += h4[j];
+  }
+  int suf = s;                                   // entries in the bins of lanes >= this one
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_down(suf, off, 64);
+    if (lane + off < 64) suf += t;
+  }
+  int run = suf - s, best = -1, left = 0;
+#pragma unroll
+  for (int j = 3; j >= 0; --j) {
+    if (best < 0 && run + h4[j] >= need) {
+      best = 4 * lane + j;
+      left = need - run;
+    }
+    run += h4[j];
+  }
+  unsigned long long packed = best >= 0 ? (static_cast<unsigned long long>(best + 1) << 32) | static_cast<uint32_t>(left) : 0ull;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) packed = umax64(packed, __shfl_xor(packed, off, 64));
+  if (lane == 0) {
+    *digit = packed != 0ull ? static_cast<int>(packed >> 32) - 1 : 0;
+    *rem = packed != 0ull ? static_cast<int>(packed & 0xFFFFFFFFull) : need;
   }
 }
 
@@ -385,15 +472,7 @@ __device__ __forceinline__ void select_by_radix(const void* base, int vocab, int
       if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
     });
     __syncthreads();
-    if (tid == 0) {
-      int rem = need, d = 255;
-      for (; d > 0; --d) {
-        if (hist[d] >= rem) break;
-        rem -= hist[d];
-      }
-      sh[0] = d;
-      sh[1] = rem;
-    }
+    if (wave == 0) radix_pick(hist, need, &sh[0], &sh[1]);
     __syncthreads();
     prefix |= static_cast<uint32_t>(sh[0]) << shift;
     mask |= 255u << shift;
@@ -467,17 +546,17 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
     const int64_t* __restrict__ seeds, const int64_t* __restrict__ steps, int chunk_vecs) {
 #pragma clang fp contract(off)
   const int row = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const void* base = LDT == MI355_F32
                          ? static_cast<const void*>(static_cast<const float*>(logits) + row * stride)
                          : static_cast<const void*>(static_cast<const uint16_t*>(logits) + row * stride);
   __shared__ unsigned long long comp[kSampleCap];
-  __shared__ uint32_t skeys[2 * kSampleThreads];
   __shared__ __align__(16) float csum[kSampleKMax];
   __shared__ unsigned long long part[kSampleThreads / 64];
   __shared__ int hist[256];
   __shared__ int eq_base[kSampleThreads / 64 + 1];
   __shared__ int sh[4];
+  __shared__ float block_tot[64];
 
   const float temp = MI355_LD(float, temperature, temperature + row);
   int k = MI355_LD(int32_t, top_k, top_k + row);
@@ -506,35 +585,55 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
   k = (k > 0 && k <= kSampleKMax) ? k : kSampleKMax;
   k = min(k, vocab);
 
-  // ---- 1. threshold guess: the k-th largest of every thread's two largest keys.  Those 2048
-  // keys are keys of distinct logits of the row and at least min(vocab, 2048) >= k of them are
-  // real (> 0), so at least k logits of the row reach the guess.
+  // ---- 1. threshold guess from every thread's two largest keys.  Those 2048 keys are keys of
+  // distinct logits of the row and at least min(vocab, 2048) >= k of them are real (> 0), so at
+  // least k logits of the row reach a value that k of the 2048 reach.
   uint32_t m1 = 0u, m2 = 0u;
   for_each_logit<LDT>(base, vocab, [&](float f, int) {
     const uint32_t key = sample_key(f);
     m2 = max(m2, min(m1, key));
     m1 = max(m1, key);
   });
-  skeys[2 * tid] = m1;
-  skeys[2 * tid + 1] = m2;
   if (tid == 0) sh[3] = 0;
-  __syncthreads();
-  bitonic_desc(skeys, 2 * kSampleThreads);
-  const uint32_t guess = skeys[k - 1];
+  // the k-th largest of the 2048 keys, to its upper 16 bits (two 8-bit radix passes in LDS); the
+  // guess is that prefix with the lower bits clear, so at least k of the keys reach it
+  uint32_t guess = 0u;
+  {
+    int need = k;
+    for (int shift = 24; shift >= 16; shift -= 8) {
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      const uint32_t above = shift == 24 ? 0u : 0xFF000000u;
+      if ((m1 & above) == (guess & above)) atomicAdd(&hist[(m1 >> shift) & 255u], 1);
+      if ((m2 & above) == (guess & above)) atomicAdd(&hist[(m2 >> shift) & 255u], 1);
+      __syncthreads();
+      if (wave == 0) radix_pick(hist, need, &sh[0], &sh[1]);
+      __syncthreads();
+      guess |= static_cast<uint32_t>(sh[0]) << shift;
+      need = sh[1];
+    }
+  }
 
-  // ---- 2. every logit at or above the guess, appended to the list one wave at a time
-  for_each_logit<LDT, 1>(base, vocab, [&](float f, int i) {
-    const uint32_t key = sample_key(f);
-    const bool take = key >= guess;
-    const unsigned long long m = __ballot(take);
-    if (m != 0ull) {
-      const int leader = __ffsll(static_cast<long long>(m)) - 1;
-      int pos = 0;
-      if (lane == leader) pos = atomicAdd(&sh[3], __popcll(m));
-      pos = __shfl(pos, leader, 64) + __popcll(m & ((1ull << lane) - 1ull));
-      if (take && pos < kSampleCap)
-        comp[pos] = (static_cast<unsigned long long>(key) << 32) |
-                    static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<uint32_t>(i));
+  // ---- 2. every logit at or above the guess goes to the list: one LDS counter bump per lane and
+  // vector that has any (a few thousand at most unless the row is degenerate)
+  for_each_vector<LDT, 2>(base, vocab, [&](const float (&f)[8], int nf, int i0) {
+    uint32_t key[8];
+    int hits = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      key[j] = j < nf ? sample_key(f[j]) : 0u;
+      hits += (j < nf && key[j] >= guess) ? 1 : 0;
+    }
+    if (hits != 0) {
+      int pos = atomicAdd(&sh[3], hits);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < nf && key[j] >= guess) {
+          if (pos < kSampleCap)
+            comp[pos] = (static_cast<unsigned long long>(key[j]) << 32) |
+                        static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<uint32_t>(i0 + j));
+          ++pos;
+        }
     }
   });
   __syncthreads();
@@ -557,48 +656,71 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
     return;
   }
   const float l0 = key_to_logit(key0);
-  if (tid < k) {
-    const float li = key_to_logit(static_cast<uint32_t>(comp[tid] >> 32));
-    float z = (li - l0) / temp;
-    if (z != z) z = -INFINITY;
-    csum[tid] = exp_det(z);
+  {
+    float w = 0.0f;
+    if (tid < k) {
+      const float li = key_to_logit(static_cast<uint32_t>(comp[tid] >> 32));
+      float z = (li - l0) / temp;
+      if (z != z) z = -INFINITY;
+      w = exp_det(z);
+    }
+    csum[tid] = w;                                   // zero beyond k: all 1024 slots take part in the sum
   }
   if (tid == 0) {
     sh[0] = k;             // keep
     sh[1] = kSampleKMax;   // pick
   }
   __syncthreads();
-  if (tid == 0) {
+  // cumulative sum in a fixed blocked order, by wave 0: lane l adds its 16 consecutive weights in
+  // sequence, lane 0 adds the 64 block totals in sequence, c[16 l + j] = offset[l] + local[l][j]
+  if (wave == 0) {
+    float4* c4 = reinterpret_cast<float4*>(csum) + 4 * lane;
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = c4[q];
     float acc = 0.0f;
-    float4* c4 = reinterpret_cast<float4*>(csum);
-    const int k4 = k >> 2;
-#pragma unroll 4
-    for (int i = 0; i < k4; ++i) {
-      float4 w = c4[i];
-      acc = acc + w.x;
-      w.x = acc;
-      acc = acc + w.y;
-      w.y = acc;
-      acc = acc + w.z;
-      w.z = acc;
-      acc = acc + w.w;
-      w.w = acc;
-      c4[i] = w;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc = acc + v[q].x;
+      v[q].x = acc;
+      acc = acc + v[q].y;
+      v[q].y = acc;
+      acc = acc + v[q].z;
+      v[q].z = acc;
+      acc = acc + v[q].w;
+      v[q].w = acc;
     }
-    for (int i = k4 << 2; i < k; ++i) {
-      acc = acc + csum[i];
-      csum[i] = acc;
+    block_tot[lane] = acc;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      float run = 0.0f;
+      for (int b = 0; b < 64; ++b) {
+        const float t = block_tot[b];
+        block_tot[b] = run;
+        run = run + t;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const float off = block_tot[lane];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[q].x = off + v[q].x;
+      v[q].y = off + v[q].y;
+      v[q].z = off + v[q].z;
+      v[q].w = off + v[q].w;
+      c4[q] = v[q];
     }
   }
   __syncthreads();
+  // first index that reaches the top-p mass / passes the target: a thread reports only a crossing
   if (tp < 1.0f) {
     const float thr = tp * csum[k - 1];
-    if (tid < k && csum[tid] >= thr) atomicMin(&sh[0], tid + 1);
+    if (tid < k && csum[tid] >= thr && (tid == 0 || !(csum[tid - 1] >= thr))) atomicMin(&sh[0], tid + 1);
     __syncthreads();
   }
   const int keep = sh[0];
   const float target = sample_uniform(seed, step) * csum[keep - 1];
-  if (tid < keep && csum[tid] > target) atomicMin(&sh[1], tid);
+  if (tid < keep && csum[tid] > target && (tid == 0 || !(csum[tid - 1] > target))) atomicMin(&sh[1], tid);
   __syncthreads();
   if (tid == 0) {
     const int pick = min(sh[1], keep - 1);
