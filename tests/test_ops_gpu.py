@@ -649,6 +649,34 @@ def test_sample_topk_topp(ops, ldt, B, V):
             assert out[2].item() == 7
 
 
+def test_sample_cut_corner_rows(ops):
+    """Rows that stress the candidate-list construction: mostly NaN, denormals around zero, a
+    vocabulary smaller than the per-thread top-2 table, one huge outlier, a sorted row."""
+    rng = rng_for("sample-corners")
+    V, B = 1504, 8
+    lg = (rng.standard_normal((B, V)) * 2).astype(np.float32)
+    lg[0, 10:] = np.nan
+    lg[1] = (rng.integers(-400, 400, V) * np.float32(1e-42)).astype(np.float32)   # denormals of both signs
+    lg[2] = np.sort(lg[2])[::-1]
+    lg[3] = np.sort(lg[3])
+    lg[4, 77] = 1e30
+    lg[5, :] = -np.inf
+    lg[5, 3] = -1e30
+    lg[6, ::2] = lg[6, 1]                                                          # half the row tied
+    temperature = np.full(B, 1.0, np.float32)
+    seeds = np.arange(B, dtype=np.int64) * 1000003
+    lgd = torch.from_numpy(lg).cuda()
+    for k, p in ((1024, 1.0), (-1, 0.9), (7, 0.5), (1000, 0.999)):
+        top_k, top_p = np.full(B, k, np.int32), np.full(B, p, np.float32)
+        for step in range(4):
+            steps = np.full(B, step, np.int64)
+            ref = R.sample_topk_topp(lg, temperature, top_k, top_p, seeds, steps)
+            out = ops.sample(lgd, torch.from_numpy(temperature).cuda(), torch.from_numpy(top_k).cuda(),
+                             torch.from_numpy(top_p).cuda(), torch.from_numpy(seeds).cuda(), torch.from_numpy(steps).cuda())
+            np.testing.assert_array_equal(out.cpu().numpy(), ref)
+            assert out[0].item() == 10 and out[5].item() == 3
+
+
 def test_sample_distribution(ops):
     """Frequencies over many (seed, step) pairs follow softmax(logits / T) over the top-k."""
     rng = rng_for("sample-dist")

@@ -588,12 +588,19 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
   // ---- 1. threshold guess from every thread's two largest keys.  Those 2048 keys are keys of
   // distinct logits of the row and at least min(vocab, 2048) >= k of them are real (> 0), so at
   // least k logits of the row reach a value that k of the 2048 reach.
-  uint32_t m1 = 0u, m2 = 0u;
+  // (floats while streaming -- five operations a logit -- keys afterwards.  A NaN is set aside as
+  // -inf and, if the thread met one, reported as the thread's largest key; a thread with fewer
+  // than two logits reports -inf for the missing ones: such stand-ins can only lower the guess.)
+  float f1 = -INFINITY, f2 = -INFINITY;
+  bool met_nan = false;
   for_each_logit<LDT>(base, vocab, [&](float f, int) {
-    const uint32_t key = sample_key(f);
-    m2 = max(m2, min(m1, key));
-    m1 = max(m1, key);
+    met_nan |= f != f;
+    const float g = f != f ? -INFINITY : f;
+    f2 = fmaxf(f2, fminf(f1, g));
+    f1 = fmaxf(f1, g);
   });
+  const uint32_t m1 = met_nan ? 0xFFFFFFFFu : sample_key(f1);
+  const uint32_t m2 = met_nan ? sample_key(f1) : sample_key(f2);
   if (tid == 0) sh[3] = 0;
   // the k-th largest of the 2048 keys, to its upper 16 bits (two 8-bit radix passes in LDS); the
   // guess is that prefix with the lower bits clear, so at least k of the keys reach it
@@ -616,21 +623,20 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
 
   // ---- 2. every logit at or above the guess goes to the list: one LDS counter bump per lane and
   // vector that has any (a few thousand at most unless the row is degenerate)
+  // (compared as floats: "not below the guess" holds for every logit whose key reaches it, for a
+  // NaN, and at most for a few denormals more -- the list may only be a superset)
+  const float guess_f = key_to_logit(guess);
   for_each_vector<LDT, 2>(base, vocab, [&](const float (&f)[8], int nf, int i0) {
-    uint32_t key[8];
     int hits = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      key[j] = j < nf ? sample_key(f[j]) : 0u;
-      hits += (j < nf && key[j] >= guess) ? 1 : 0;
-    }
+    for (int j = 0; j < 8; ++j) hits += (j < nf && !(f[j] < guess_f)) ? 1 : 0;
     if (hits != 0) {
       int pos = atomicAdd(&sh[3], hits);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        if (j < nf && key[j] >= guess) {
+        if (j < nf && !(f[j] < guess_f)) {
           if (pos < kSampleCap)
-            comp[pos] = (static_cast<unsigned long long>(key[j]) << 32) |
+            comp[pos] = (static_cast<unsigned long long>(sample_key(f[j])) << 32) |
                         static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<uint32_t>(i0 + j));
           ++pos;
         }
@@ -638,7 +644,7 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
   });
   __syncthreads();
   const int n = sh[3];
-  if (n <= kSampleCap) {
+  if (n >= k && n <= kSampleCap) {
     int P = 64;
     while (P < n) P <<= 1;
     for (int i = n + tid; i < P; i += kSampleThreads) comp[i] = 0ull;
