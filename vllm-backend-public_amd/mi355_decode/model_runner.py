@@ -170,6 +170,15 @@ class ModelRunner:
         self.h_lp = [torch.zeros(B, 1 + 2 * self.MAX_LOGPROBS, dtype=torch.float32).pin_memory()
                      for _ in range(self.NUM_STAGES)]
         self.h64, self.h32, self.h_next = self.h64s[0], self.h32s[0], self.h_nexts[0]
+        # sampling parameters of a decode step, packed so that one copy ships them:
+        # seeds i64 | steps i64 | temperature f32 | top_p f32 | top_k i32, B entries each
+        self.h_samp = [torch.zeros(28 * B, dtype=torch.uint8).pin_memory() for _ in range(self.NUM_STAGES)]
+        self.d_samp = torch.zeros(28 * B, dtype=torch.uint8, device=self.device)
+        cut = lambda buf: (buf[:8 * B].view(torch.int64), buf[8 * B:16 * B].view(torch.int64),      # noqa: E731
+                           buf[16 * B:20 * B].view(torch.float32), buf[20 * B:24 * B].view(torch.float32),
+                           buf[24 * B:].view(torch.int32))
+        self.h_samp_np = [tuple(v.numpy() for v in cut(h)) for h in self.h_samp]
+        self.d_samp_views = cut(self.d_samp)
 
     # ------------------------------------------------------------------ #
     KINDS = ("qkv", "o", "gu", "down", "lm_head")
@@ -742,8 +751,19 @@ class ModelRunner:
         """numpy views of one set of pinned staging buffers, laid out like in64 / in32."""
         return self.h64s[stage].numpy(), self.h32s[stage].numpy()
 
-    def _sample(self, logits: torch.Tensor, sampling: dict, out: torch.Tensor) -> None:
-        """Re-draw the rows that asked for random sampling (greedy rows keep argmax)."""
+    def _sample(self, logits: torch.Tensor, sampling: dict, out: torch.Tensor, stage: Optional[int] = None) -> None:
+        """Draw every row's token per its sampling parameters (greedy where temperature <= 0).
+        With `stage` (a decode step) the parameters travel in that staging set's packed pinned
+        buffer, one copy; without (a prefill, which waits for its result anyway) array by array."""
+        n = logits.shape[0]
+        if stage is not None:
+            seeds, steps, temp, top_p, top_k = self.h_samp_np[stage]
+            seeds[:n], steps[:n] = sampling["seeds"], sampling["steps"]
+            temp[:n], top_p[:n], top_k[:n] = sampling["temperature"], sampling["top_p"], sampling["top_k"]
+            self.d_samp.copy_(self.h_samp[stage], non_blocking=True)
+            d_seeds, d_steps, d_temp, d_top_p, d_top_k = self.d_samp_views
+            ops.sample(logits, d_temp[:n], d_top_k[:n], d_top_p[:n], d_seeds[:n], d_steps[:n], out=out)
+            return
         dev = self.device
         t = lambda a, dt: torch.from_numpy(a).to(dev, dtype=dt, non_blocking=True)  # noqa: E731
         ops.sample(logits, t(sampling["temperature"], torch.float32), t(sampling["top_k"], torch.int32),
@@ -788,7 +808,7 @@ class ModelRunner:
         if sampling is not None or logprobs >= 0:
             logits = self.full_logits(self.logits[:batch])
         if sampling is not None:
-            self._sample(logits, sampling, nxt)
+            self._sample(logits, sampling, nxt, stage)
         self._ids_synced = sampling is None          # re-drawn rows are in next_ids only
         self.h_nexts[stage][:batch].copy_(nxt, non_blocking=True)
         if logprobs >= 0:
