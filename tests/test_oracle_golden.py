@@ -271,3 +271,37 @@ def test_full_vocabulary_draw_follows_the_softmax():
     lg[1, 40] = -3.0
     out = R.sample_topk_topp(lg, np.ones(3, np.float32), np.zeros(3, np.int32), np.ones(3, np.float32), [1, 2, 3], [0, 0, 0])
     assert out[0] == 9 and out[1] == 40 and 0 <= out[2] < 64
+
+
+def test_blocked_cumsum_is_a_cumulative_sum():
+    rng = np.random.default_rng(13)
+    for k in (1, 2, 15, 16, 17, 50, 1000, 1024):
+        w = rng.random(k).astype(np.float32) ** 4
+        c = R.blocked_cumsum(w)
+        want = np.cumsum(w.astype(np.float64))
+        assert c.dtype == np.float32 and c.shape == (k,)
+        assert np.abs(c - want).max() <= 2e-6 * want[-1] + 1e-30
+        assert (np.diff(c) >= 0).all()                     # never decreasing: the inverse-CDF search relies on it
+    assert R.blocked_cumsum(np.zeros(7, np.float32)).tolist() == [0.0] * 7
+
+
+def test_top_p_and_top_k_cut_the_candidates():
+    """The restatement's cut semantics on a row small enough to enumerate: top-k keeps k tokens,
+    top-p the shortest prefix reaching the mass, and no draw ever leaves the kept set."""
+    rng = np.random.default_rng(14)
+    V, n = 50, 4000
+    row = (rng.standard_normal(V) * 2).astype(np.float32)
+    order = np.argsort(-row, kind="stable")
+    p = np.exp(row[order].astype(np.float64))
+    p /= p.sum()
+    lg = np.tile(row, (n, 1))
+    ones = np.ones(n, np.float32)
+    for k, tp in ((5, 1.0), (-1, 0.7), (10, 0.5)):
+        kk = k if k > 0 else V
+        pk = p[:kk] / p[:kk].sum()
+        keep = kk if tp >= 1 else int(np.argmax(np.cumsum(pk) >= tp * (1 - 1e-6))) + 1
+        ids = R.sample_topk_topp(lg, ones, np.full(n, k, np.int32), ones * tp, np.arange(n) + 99, np.arange(n) % 13)
+        assert set(ids) <= set(order[:keep].tolist())
+        q = pk[:keep] / pk[:keep].sum()
+        freq = np.array([(ids == t).mean() for t in order[:keep]])
+        assert np.abs(freq - q).max() < 4 * np.sqrt(q.max() / n) + 0.01
