@@ -43,6 +43,19 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak
 
 
+def baseline_config_label(a, fp8_weights) -> str:
+    """Which entry of BASELINE.json's `configs` the run is, if any."""
+    shape = (a.model, a.batch_per_gpu, a.prompt_len, a.gen_len, bool(fp8_weights))
+    if shape == ("llama-3-8b", 32, 128, 128, False):
+        return f"BASELINE.json configs[{1 if a.gpus == 1 else 2}]"
+    if shape == ("qwen2-7b", 64, 512, 512, True) and a.gpus == 1:
+        return "BASELINE.json configs[4]"
+    if a.model == "llama-3-70b" and (a.prompt_len, a.gen_len) == (2048, 256) and not fp8_weights:
+        return ("BASELINE.json configs[3]" if a.gpus == 8 and a.batch_per_gpu == 2 else
+                f"the model and request shape of BASELINE.json configs[3] on {a.gpus} GPU(s), not that config's TP=8")
+    return "not one of BASELINE.json's configs"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -615,7 +628,7 @@ def main():
         "vs_baseline": None, "dtype": ("bf16" if a.dtype == "bfloat16" else a.dtype) + ("+fp8w" if lwe else ""),
         "data": "synthetic",
         "config": {"workload": f"{a.model} decode, batch {batch} ({a.batch_per_gpu}/GPU), {P}-in/{G}-out, greedy, "
-                               f"synthetic weights and token-id prompts; BASELINE.json configs[{1 if a.gpus == 1 else 2}]",
+                               f"synthetic weights and token-id prompts; " + baseline_config_label(a, lwe),
                    "global_batch": batch, "prompt_len": P, "gen_len": G,
                    "parallelism": (f"tp{tp} (attention heads and MLP sharded, two all-reduces per layer; lm_head "
                                    + ("sharded over the vocabulary, greedy keys max-reduced)" if vocab_tp > 1 else "replicated)")
