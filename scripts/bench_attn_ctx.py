@@ -5,8 +5,9 @@ sys.path.insert(0, "vllm-backend-public_amd")
 from mi355_decode import ops
 
 dev, dt = "cuda", torch.bfloat16
-B, nh, nkv, d, L = 32, 32, 8, 128, 16
-MAXCTX = 2048
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32          # sequences
+nh, nkv, d, L = (int(sys.argv[2]) if len(sys.argv) > 2 else 32), 8, 128, 16
+MAXCTX = 2304
 blocks_per_seq = MAXCTX // 16
 nb = B * blocks_per_seq
 kc = [torch.randn(nb, nkv, 16, d, dtype=dt, device=dev) for _ in range(L)]
@@ -35,7 +36,7 @@ def timed(fn):
     return s.elapsed_time(e) * 1000 / (5 * 4 * L)
 
 
-for c in (1, 32, 128, 192, 256, 512, 1024, 2048):
+for c in ((1, 32, 128, 192, 256, 512, 1024, 2048) if len(sys.argv) <= 3 else tuple(int(x) for x in sys.argv[3].split(","))):
     ctx = torch.full((B,), c, dtype=torch.int32, device=dev)
     line = []
     for sp in (1, 2, 4, 8):
