@@ -129,9 +129,41 @@ def engine_generation():
     return out
 
 
+def sampler_rows():
+    """The sampling launch on exactly sized logits (no slack behind the last row), every kind of
+    row in one call: greedy, whole-vocabulary draw, top-k / top-p cuts, an all-tied row (the list
+    overflows: radix select), a mostly-NaN row; vocabularies with and without a vector tail."""
+    from mi355_decode import ops
+    done = []
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for dt in (torch.bfloat16, torch.float16, torch.float32):
+        for B, V in ((9, 128256), (5, 1000), (33, 50272), (4, 72)):
+            lg = (torch.randn(B, V, generator=g) * 3).to(dt)
+            lg[1] = 0.0
+            lg[2, 5:] = float("nan")
+            lgd = lg.cuda()
+            temp = torch.tensor([0.0, 0.7, 1.0, 1.3] * 9)[:B].cuda()
+            top_k = torch.tensor([-1, 40, 1024, -1, 7] * 8, dtype=torch.int32)[:B].cuda()
+            top_p = torch.tensor([1.0, 0.9, 1.0, 0.5, 1.0, 1.0, 0.95] * 6)[:B].cuda()
+            seeds = torch.arange(B, dtype=torch.int64).cuda()
+            steps = torch.arange(B, dtype=torch.int64).cuda() * 3
+            out = torch.empty(B, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            bounds.sync_allocations()
+            ops.sample(lgd, temp, top_k, top_p, seeds, steps, out=out)
+            torch.cuda.synchronize()
+            rep = bounds.report()
+            assert rep is None, (str(dt), B, V, rep)
+            assert int(out.min()) >= 0 and int(out.max()) < V
+            done.append(f"{str(dt).split('.')[-1]}:{B}x{V}")
+            bounds.clear()
+    return done
+
+
 if __name__ == "__main__":
     assert bounds.enabled(), "not the bounds-checking build: set MI355_DECODE_LIB"
     res = {"negative_control": negative_control()}
+    res["sampler"] = sampler_rows()
     res["rank_steps"] = rank_steps()
     res["engine"] = engine_generation()
     print(json.dumps(res))
