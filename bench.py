@@ -4,8 +4,15 @@ workload: Llama-3-8B geometry, bf16, batch 32 per GPU, 128 tokens in / 128 out,
 synthetic weights and token-id prompts.
 
     python bench.py --gpus 1 --steps 127 --warmup 10
+    python bench.py --gpus 4 --steps 127 --warmup 10          # starts its own 4 ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 4 --steps 127 --warmup 10
+
+The tensor-parallel degree reaches the engine as a bare integer and nothing upstream
+starts ranks (benchmark-vllm/vllm_templates.py:55), so `--gpus N` outside a launcher
+starts N rank processes itself, like the server does: the parent touches no GPU, gives
+each child RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, relays rank 0's JSON line and
+exits non-zero if any rank did.
 
 A "step" is one engine decode step: every running sequence advances one token
 (scheduler bookkeeping, two small host-to-device copies, one HIP-graph replay of
@@ -54,6 +61,57 @@ def baseline_config_label(a, fp8_weights) -> str:
         return ("BASELINE.json configs[3]" if a.gpus == 8 and a.batch_per_gpu == 2 else
                 f"the model and request shape of BASELINE.json configs[3] on {a.gpus} GPU(s), not that config's TP=8")
     return "not one of BASELINE.json's configs"
+
+
+def launch_ranks(n, cmd, env=None, timeout=None):
+    """Start `cmd` n times as rank processes of one job on this node (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR=127.0.0.1, a free MASTER_PORT) and wait for all of them.
+    The caller must not have initialised a GPU: the children are fresh processes, nothing is
+    exec'ed over this one.  Rank 0's stdout is captured and returned; the other ranks' stdout
+    goes to this process's stderr, everyone's stderr is inherited.  A rank that exits non-zero
+    ends the others (they would wait in a collective for it).  Returns (exit code, rank 0's
+    stdout): the first non-zero exit code of any rank, else 0."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ if env is None else env, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen(list(cmd), env=dict(base, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=subprocess.PIPE if r == 0 else 2, text=True))   # 2: this process's stderr
+    out0, rc, t_end = [], 0, (time.time() + timeout if timeout else None)
+    import threading
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                print(f"bench: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+        if live and (rc != 0 or (t_end and time.time() > t_end)):
+            rc = rc or 124
+            for r in live:
+                procs[r].terminate()
+            deadline = time.time() + 10
+            for r in live:
+                try:
+                    procs[r].wait(timeout=max(deadline - time.time(), 0.1))
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+                    procs[r].wait()
+            live.clear()
+        if live:
+            time.sleep(0.05)
+    reader.join(timeout=10)
+    return rc, (out0[0] if out0 else "")
 
 
 def parse():
@@ -507,6 +565,13 @@ def pmc_traffic(tiled):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher above us: become the parent of a.gpus rank processes (nothing GPU-related has
+        # been imported yet) and relay rank 0's line
+        rc, out = launch_ranks(a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        raise SystemExit(rc)
     import torch
     import torch.distributed as dist
     from mi355_decode.config import EngineArgs, ModelConfig
@@ -516,7 +581,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} under a launcher that started {world} rank(s): the two must agree")
     tp = a.gpus
     batch = a.batch_per_gpu * a.gpus
     P, G = a.prompt_len, a.gen_len
@@ -667,6 +732,22 @@ def main():
                                         "one-shot kernel over IPC-mapped buffers" if r_.oneshot is not None else
                                         ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal)")),
                           "gemm_form": {k: ("tiled" if v else "library") for k, v in r_._mode(batch).items()}}
+
+    # what the job really ran on: ranks the process group saw, its backend, every rank's device
+    mine = {"rank": rank, "device": torch.cuda.get_device_name(engine.device), "index": engine.device.index,
+            "pid": os.getpid()}
+    if world > 1:
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        result["ranks_seen"] = dist.get_world_size()
+        result["dist_backend"] = dist.get_backend()
+    else:
+        seen = [mine]
+        result["ranks_seen"] = 1
+        result["dist_backend"] = None
+    result["rank_devices"] = seen
+    result["launched_by"] = "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else (
+        "bench.py itself" if world > 1 else "single process")
 
     kern = None
     if rank == 0 and not a.no_kernel_timing:

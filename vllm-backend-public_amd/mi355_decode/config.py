@@ -138,7 +138,15 @@ class ModelConfig:
         path = os.path.join(model, "config.json")
         if os.path.isfile(path):
             with open(path) as f:
-                return cls.from_dict(json.load(f))
+                cfg = cls.from_dict(json.load(f))
+            # generation_config.json may name more end-of-sequence ids than config.json (Llama-3
+            # instruct: <|end_of_text|> in one, <|eot_id|> too in the other): generation stops on any
+            gen = os.path.join(model, "generation_config.json")
+            if os.path.isfile(gen):
+                with open(gen) as f:
+                    more = json.load(f).get("eos_token_id")
+                cfg.eos_token_id = merge_eos(cfg.eos_token_id, more)
+            return cfg
         key = _known_key(model)
         if key is not None:
             return cls.from_dict(KNOWN_MODELS[key])
@@ -155,6 +163,16 @@ class ModelConfig:
             return L * per_layer + V * H + (self.max_position_embeddings + self.position_offset) * H + 2 * H
         per_layer = qkv + o + 3 * F * H + 2 * H
         return L * per_layer + V * H * (1 if self.tie_word_embeddings else 2) + H
+
+
+def merge_eos(*values) -> Any:
+    """Union of end-of-sequence ids given as None, an int or a list, first-seen order; None if empty."""
+    out = []
+    for v in values:
+        for t in ([] if v is None else (list(v) if isinstance(v, (list, tuple)) else [v])):
+            if isinstance(t, int) and not isinstance(t, bool) and t not in out:
+                out.append(t)
+    return None if not out else (out[0] if len(out) == 1 else out)
 
 
 _DTYPES = {"auto": "bfloat16", "bfloat16": "bfloat16", "bf16": "bfloat16", "half": "float16",

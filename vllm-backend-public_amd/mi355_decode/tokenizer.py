@@ -19,7 +19,7 @@ class ByteTokenizer:
         self.bos_token_id = None
         self.eos_token_id = None
 
-    def encode(self, text: str) -> List[int]:
+    def encode(self, text: str, add_special_tokens: bool = True) -> List[int]:
         ids = [(b + self.offset) % self.vocab_size for b in text.encode("utf-8")]
         return ids or [self.offset % self.vocab_size]
 
@@ -31,15 +31,22 @@ class ByteTokenizer:
 class HFTokenizer:
     is_fallback = False
 
-    def __init__(self, path: str, add_bos: bool = True):
+    def __init__(self, path: str):
         from tokenizers import Tokenizer
         self.tk = Tokenizer.from_file(path)
         self.vocab_size = self.tk.get_vocab_size()
-        self.bos_token_id = None
-        self.eos_token_id = None
+        self.bos_token = self.eos_token = None
+        self.bos_token_id = self.eos_token_id = None
+        self.chat_template = None
 
-    def encode(self, text: str) -> List[int]:
-        return self.tk.encode(text, add_special_tokens=True).ids
+    def encode(self, text: str, add_special_tokens: bool = True) -> List[int]:
+        """add_special_tokens=False: the tokenizer.json post-processor (the BOS a Llama-3 tokenizer
+        prepends) is skipped -- for text that already spells its special tokens out, such as a
+        rendered chat template.  Special tokens written in the text are recognised either way."""
+        return self.tk.encode(text, add_special_tokens=add_special_tokens).ids
+
+    def token_to_id(self, token):
+        return None if token is None else self.tk.token_to_id(token)
 
     def decode(self, ids: List[int]) -> str:
         return self.tk.decode(list(ids), skip_special_tokens=True)
@@ -57,7 +64,9 @@ def load_tokenizer(model: str, vocab_size: int):
             tk.chat_template = meta.get("chat_template") if isinstance(meta.get("chat_template"), str) else None
             for key in ("bos_token", "eos_token"):
                 v = meta.get(key)
-                setattr(tk, key, v.get("content") if isinstance(v, dict) else v)
+                v = v.get("content") if isinstance(v, dict) else v
+                setattr(tk, key, v if isinstance(v, str) else None)
+                setattr(tk, key + "_id", tk.token_to_id(getattr(tk, key)))
         return tk
     return ByteTokenizer(vocab_size)
 

@@ -160,8 +160,22 @@ def _opt_only_one_gpu(tp_size: int) -> None:
 
 
 def _opt_from_getter(cfg: ModelConfig, get, dtype, device, tp_size: int, num_layers: Optional[int]) -> ModelWeights:
-    """HF OPT parameter names (model.decoder.*; transformers models/opt/modeling_opt.py)."""
+    """HF OPT parameter names (model.decoder.*; transformers models/opt/modeling_opt.py).  Some
+    published OPT checkpoints store the decoder without the `model.` prefix (`decoder.*`) next to a
+    separate, tied `lm_head.weight`: both namings load, the lm_head copy is not read."""
     _opt_only_one_gpu(tp_size)
+    get_as_named = get
+
+    def get(name):                                       # noqa: F811  model.decoder.X, else decoder.X
+        try:
+            return get_as_named(name)
+        except KeyError:
+            if not name.startswith("model."):
+                raise
+            try:
+                return get_as_named(name[len("model."):])
+            except KeyError:
+                raise KeyError(f"{name} (or {name[len('model.'):]}) not found in the checkpoint") from None
 
     def put(t: torch.Tensor) -> torch.Tensor:
         return t.to(dtype).contiguous().to(device)
