@@ -569,8 +569,10 @@ def main():
         # no launcher above us: become the parent of a.gpus rank processes (nothing GPU-related has
         # been imported yet) and relay rank 0's line
         rc, out = launch_ranks(a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
-        sys.stdout.write(out)
-        sys.stdout.flush()
+        # stdout carries the result line only: what a collective library printed there (gloo's
+        # connection notes, RCCL's debug output) goes to stderr
+        for line in out.splitlines():
+            print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
         raise SystemExit(rc)
     import torch
     import torch.distributed as dist

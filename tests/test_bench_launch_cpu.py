@@ -71,7 +71,7 @@ def test_gpus_n_without_launcher_spawns_and_relays(monkeypatch, capsys):
 
     def fake(n, cmd, env=None, timeout=None):
         calls.append((n, cmd))
-        return 0, '{"metric": "decode_tok_s"}\n'
+        return 0, '[Gloo] chatter\n{"metric": "decode_tok_s"}\n'
 
     monkeypatch.setattr(bench, "launch_ranks", fake)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
@@ -81,4 +81,5 @@ def test_gpus_n_without_launcher_spawns_and_relays(monkeypatch, capsys):
     assert ei.value.code == 0
     (n, cmd), = calls
     assert n == 4 and cmd[0] == sys.executable and cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "4", "--steps", "3"]
-    assert capsys.readouterr().out == '{"metric": "decode_tok_s"}\n'
+    cap = capsys.readouterr()
+    assert cap.out == '{"metric": "decode_tok_s"}\n' and "[Gloo] chatter" in cap.err
