@@ -154,7 +154,11 @@ def test_rank_decode_step_matches_oracle(case):
         # ... so it can leave the oracle's only where the oracle's margin is inside twice the logit error
         # (random weights give flat logits: near-ties are common, 2 of 16 rows were seen)
         assert (gaps >= 0).all() and (gaps <= 2 * err.max() + 1e-6).all()
-        assert same.mean() >= 0.75
     err = np.abs(lt - ll)
     assert err.max() <= MAX_TOL * scale and err.mean() <= MEAN_TOL * scale
-    assert (tt == tl).mean() >= 0.75
+    # the two GEMM forms may pick different tokens only where the margin between the two picks, in either
+    # form's logits, is inside twice the difference between the forms
+    rows = np.flatnonzero(tt != tl)
+    off = rank * want.shape[1] if shard_mlp else 0
+    assert (np.abs(lt[rows, tt[rows] - off] - lt[rows, tl[rows] - off]) <= 2 * err.max() + 1e-6).all()
+    print(f"{case[0]}: {int((tt == tl).sum())}/{len(tt)} greedy tokens equal between the tiled and the library GEMM path")

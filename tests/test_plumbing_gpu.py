@@ -140,3 +140,157 @@ def test_harness_plumbing_pass(tmp_path, case, tp):
             pass
         stub.shutdown()
         log.close()
+
+
+def _oracle_generation(cfg, w, prompt_ids, gen):
+    """Greedy tokens of the numpy oracle for one prompt, every step's logits, and every step's top-2
+    margin relative to the logit scale."""
+    import numpy as np
+    from oracle import model_ref as M
+    model = M.RefModel(M.RefConfig(**cfg), w, "bfloat16", num_blocks=16)
+    toks, logits = M.greedy_generate(model, [np.asarray(prompt_ids, dtype=np.int64)], gen)
+    scale = float(np.abs(logits[0]).max())
+    margins = [float(np.sort(lg[0])[-1] - np.sort(lg[0])[-2]) / scale for lg in logits]
+    return [int(t) for t in toks[0]], [lg[0] for lg in logits], margins, scale
+
+
+def test_real_model_directory_end_to_end(tmp_path):
+    """The only thing the harness ever serves is a local checkpoint directory
+    (/root/reference/benchmark-mlflow/vllm_processor.py:29; polled at /root/reference/benchmark-eval/main.py:105).
+    One is built here from nothing -- sharded safetensors + index, tokenizer.json trained in memory,
+    tokenizer_config.json with a chat template, config.json + generation_config.json with a LIST of
+    end-of-sequence ids -- and served: text goes in, text comes out and equals tokenizer.decode(oracle
+    tokens); generation stops on an end-of-sequence id from either file; a stop string that straddles
+    two tokens cuts the text; the chat route renders the template (one BOS)."""
+    import torch
+    assert torch.cuda.is_available()
+    from mi355_decode.harness import BenchClient
+    from mi355_decode.tokenizer import load_tokenizer
+    from real_model_fixture import BOS, CORPUS, EOT, build_model_dir
+    from test_model_gpu import LOGIT_TOL
+
+    model_dir = str(tmp_path / "tiny-llama-real")
+    cfg, w, _ = build_model_dir(model_dir, "llama_d128", shards=3)
+    tok = load_tokenizer(model_dir, cfg["vocab_size"])
+    GEN = 8
+    # prompts whose oracle generation has a clear margin at every step (2^-5 of the logit scale, the bound
+    # on the worst single logit of a bf16 step), so that the served text can be held to the oracle's exactly
+    texts, gens = [], []
+    for text in CORPUS:
+        toks, _, margins, _ = _oracle_generation(cfg, w, tok.encode(text), GEN)
+        if min(margins) >= 2.0 ** -5 and 1 not in toks:
+            texts.append(text)
+            gens.append(toks)
+    assert len(texts) >= 3, "too few prompts with clear oracle margins"
+    # end-of-sequence ids: config.json names a token the SECOND prompt's generation reaches, generation_config.json
+    # one the FIRST prompt's reaches (and not the other way round, nor before)
+    y = next(t for i, t in enumerate(gens[0][2:]) if t not in gens[0][:i + 2] and t not in gens[1])
+    z = next(t for i, t in enumerate(gens[1][2:]) if t not in gens[1][:i + 2] and t not in gens[0] and t != y)
+    full = json.load(open(os.path.join(model_dir, "config.json")))
+    full["eos_token_id"] = z
+    json.dump(full, open(os.path.join(model_dir, "config.json"), "w"))
+    json.dump({"eos_token_id": [y, 1]}, open(os.path.join(model_dir, "generation_config.json"), "w"))
+
+    port = free_port()
+    args = ["--model", model_dir, "--served-model-name", "tiny-real", "--host", "127.0.0.1", "--port", str(port),
+            "--dtype", "bfloat16", "--max-num-seqs", "8", "--max-model-len", "256", "--tensor-parallel-size", "1",
+            "--load-format", "auto"]
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + ROOT)
+    log = open(tmp_path / "server.log", "w")
+    proc = subprocess.Popen([sys.executable, "-m", "mi355_decode.entrypoints.openai.api_server"] + args,
+                            env=env, stdout=log, stderr=subprocess.STDOUT, start_new_session=True)
+    url = f"http://127.0.0.1:{port}"
+    try:
+        client = BenchClient(url)
+        t0 = time.time()
+        while True:
+            assert proc.poll() is None, open(tmp_path / "server.log").read()[-3000:]
+            try:
+                if client.health() == 200:
+                    break
+            except Exception:
+                pass
+            assert time.time() - t0 < 240, "server did not become healthy"
+            time.sleep(0.2)
+        assert client.wait_ready(tries=30, delay=0.5) == "tiny-real"
+        card = client.http.get(f"{url}/v1/models").json()["data"][0]
+        assert card["dtype"] == "bfloat16" and card["dtype_downgraded"] is False
+        post = lambda route, **body: client.http.post(f"{url}{route}", json={"model": "tiny-real", **body})   # noqa: E731
+
+        # text in, text out == decode(oracle tokens); the weights came from the safetensors shards, not a seed
+        for text, toks in zip(texts, gens):
+            r = post("/v1/completions", prompt=text, max_tokens=GEN, temperature=0, ignore_eos=True)
+            assert r.status_code == 200, r.text
+            assert r.json()["choices"][0]["text"] == tok.decode(toks), text
+            assert r.json()["usage"]["prompt_tokens"] == len(tok.encode(text))
+        text_log = open(tmp_path / "server.log").read()
+        assert "synthetic" not in text_log and "byte-wise" not in text_log, text_log[-2000:]
+
+        # a longer generation, by token id (return_tokens_as_token_ids): the text is the decoding of the very tokens
+        # the engine produced, and those leave the oracle's only at a near-tie of the oracle's logits
+        LONG = 24
+        want, logits, _, scale = _oracle_generation(cfg, w, tok.encode(texts[0]), LONG)
+        r = post("/v1/completions", prompt=texts[0], max_tokens=LONG, temperature=0, ignore_eos=True, logprobs=0,
+                 return_tokens_as_token_ids=True)
+        ch = r.json()["choices"][0]
+        got = [int(t.split(":")[1]) for t in ch["logprobs"]["tokens"]]
+        assert len(got) == LONG and ch["text"] == tok.decode(got)
+        for t in range(LONG):
+            if got[t] != want[t]:
+                gap = logits[t][want[t]] - logits[t][got[t]]
+                assert 0 <= gap <= 2 * LOGIT_TOL["bfloat16"] * scale, f"step {t}: {got[t]} vs oracle {want[t]}, margin {gap}"
+                break
+
+        # end-of-sequence ids from either file end the generation (the id itself counted, not shown)
+        for text, toks, eos in ((texts[0], gens[0], y), (texts[1], gens[1], z)):
+            r = post("/v1/completions", prompt=text, max_tokens=GEN, temperature=0)
+            ch, n = r.json()["choices"][0], toks.index(eos) + 1
+            assert ch["finish_reason"] == "stop" and r.json()["usage"]["completion_tokens"] == n
+            assert ch["text"] == tok.decode(toks[:n - 1])
+
+        # a stop string across a token boundary (two tokens with plain ASCII text), plain and streamed
+        found = None
+        for text, toks in zip(texts, gens):
+            pieces = [tok.decode(toks[:k + 1])[len(tok.decode(toks[:k])):] for k in range(GEN)]
+            whole = "".join(pieces)
+            for i in range(1, GEN - 1):
+                a, b = pieces[i], pieces[i + 1]
+                if a and b and (a + b).isascii() and whole.find(a[-1:] + b[:1]) == len("".join(pieces[:i + 1])) - 1:
+                    found = (text, whole, a[-1:] + b[:1])
+                    break
+            if found:
+                break
+        assert found, "no pair of adjacent ASCII pieces in the oracle generations"
+        stop_prompt, whole, stop = found
+        r = post("/v1/completions", prompt=stop_prompt, max_tokens=GEN, temperature=0, ignore_eos=True, stop=stop)
+        assert r.json()["choices"][0]["finish_reason"] == "stop"
+        assert r.json()["choices"][0]["text"] == whole[:whole.find(stop)]
+        with client.http.post(f"{url}/v1/completions", stream=True,
+                              json={"model": "tiny-real", "prompt": stop_prompt, "max_tokens": GEN, "temperature": 0,
+                                    "ignore_eos": True, "stop": [stop], "stream": True}) as r:
+            lines = [ln.decode() for ln in r.iter_lines() if ln]
+        chunks = [json.loads(ln[6:]) for ln in lines if ln != "data: [DONE]"]
+        assert "".join(c["choices"][0]["text"] for c in chunks) == whole[:whole.find(stop)]
+
+        # chat: the directory's template, tokenised without a second BOS
+        msgs = [{"role": "user", "content": texts[0]}]
+        rendered = f"{BOS}<|user|>\n{texts[0]}{EOT}\n<|assistant|>\n"
+        ids = tok.encode(rendered, add_special_tokens=False)
+        assert ids.count(tok.bos_token_id) == 1
+        want, _, margins, _ = _oracle_generation(cfg, w, ids, 4)
+        r = post("/v1/chat/completions", messages=msgs, max_tokens=4, temperature=0, ignore_eos=True)
+        assert r.status_code == 200, r.text
+        assert r.json()["usage"]["prompt_tokens"] == len(ids)
+        if min(margins) >= 2.0 ** -5:
+            assert r.json()["choices"][0]["message"]["content"] == tok.decode(want)
+    finally:
+        proc.terminate()
+        try:
+            proc.wait(30)
+        except subprocess.TimeoutExpired:
+            pass
+        try:
+            os.killpg(proc.pid, 9)
+        except ProcessLookupError:
+            pass
+        log.close()

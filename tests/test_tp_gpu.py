@@ -134,4 +134,5 @@ def test_two_ranks_generate_like_the_unsharded_oracle(name, dtype, shard_mlp, on
     exact = compare_tokens(t0, ref_tokens, ref_logits, 2 * LOGIT_TOL[dtype] * scale)
     print(f"{name} {dtype} tp2 {'mlp sharded' if shard_mlp else 'mlp replicated'}: "
           f"{exact}/{ref_tokens.size} tokens equal to the unsharded oracle")
-    assert exact >= 0.6 * ref_tokens.size
+    # the bar is compare_tokens' margin rule alone: a sequence may leave the oracle's only at a step where
+    # the oracle's own margin is inside the logit-error bound (after which it is a different generation)

@@ -75,20 +75,39 @@ def render_chat(messages, tokenizer) -> str:
             raise ValueError("message content must be a string or a list of text parts")
     template = getattr(tokenizer, "chat_template", None)
     if template:
+        # the template comes with the model directory, i.e. from whoever published the model: it is
+        # rendered in a sandbox (no attribute walks into Python internals, no mutation of what it is
+        # handed), with the two helpers published templates call
+        import datetime
         import jinja2
-        env = jinja2.Environment(trim_blocks=True, lstrip_blocks=True)
-        return env.from_string(template).render(messages=messages, add_generation_prompt=True,
-                                                bos_token=getattr(tokenizer, "bos_token", "") or "",
-                                                eos_token=getattr(tokenizer, "eos_token", "") or "")
+        import jinja2.sandbox
+
+        def raise_exception(message):
+            raise jinja2.TemplateError(message)
+
+        env = jinja2.sandbox.ImmutableSandboxedEnvironment(trim_blocks=True, lstrip_blocks=True)
+        env.globals["raise_exception"] = raise_exception
+        env.globals["strftime_now"] = lambda fmt: datetime.datetime.now().strftime(fmt)
+        try:
+            return env.from_string(template).render(messages=messages, add_generation_prompt=True,
+                                                    bos_token=getattr(tokenizer, "bos_token", "") or "",
+                                                    eos_token=getattr(tokenizer, "eos_token", "") or "")
+        except jinja2.TemplateError as exc:               # incl. SecurityError: the request cannot be rendered
+            raise ValueError(f"chat template: {exc}") from None
     return "".join(f"<|{m['role']}|>\n{m['content']}\n\n" for m in messages) + "<|assistant|>\n"
 
 
-def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int, max_model_len: int):
+def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int, max_model_len: int,
+              requested_dtype: Optional[str] = None, served_dtype: Optional[str] = None):
+    """requested_dtype / served_dtype: what --dtype asked for and the arithmetic type the kernels
+    run in.  The harness's default config asks for float32 (benchmark-vllm/models.py:14); this
+    engine computes in 16 bits, and /v1/models and /metrics say so instead of leaving it to a log line."""
     from ...sampling_params import SamplingParams
     from ...tokenizer import IncrementalDetokenizer
 
     app = FastAPI(title="mi355-decode", version="0.1.0")
     created = int(time.time())
+    dtype_downgraded = (requested_dtype or "").lower() in ("float32", "float")
 
     def not_ready():
         if engine_thread.failed is not None:
@@ -116,9 +135,11 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
         bad = not_ready()
         if bad is not None:
             return bad
-        return {"object": "list", "data": [{"id": served_model_name, "object": "model", "created": created,
-                                            "owned_by": "mi355-decode", "root": served_model_name,
-                                            "parent": None, "max_model_len": max_model_len}]}
+        card = {"id": served_model_name, "object": "model", "created": created, "owned_by": "mi355-decode",
+                "root": served_model_name, "parent": None, "max_model_len": max_model_len}
+        if served_dtype is not None:
+            card.update(dtype=served_dtype, requested_dtype=requested_dtype, dtype_downgraded=dtype_downgraded)
+        return {"object": "list", "data": [card]}
 
     @app.get("/metrics")
     async def metrics():
@@ -126,6 +147,9 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
         lines = [f"mi355_engine_steps_total {engine_thread.steps}",
                  f"mi355_generation_tokens_total {engine_thread.tokens_out}",
                  f"mi355_uptime_seconds {time.time() - engine_thread.started:.1f}"]
+        if served_dtype is not None:
+            lines += [f'mi355_served_dtype{{dtype="{served_dtype}",requested="{requested_dtype}"}} 1',
+                      f"mi355_dtype_downgraded {int(dtype_downgraded)}"]
         if eng is not None:
             lines += [f"mi355_num_requests_running {len(eng.sched.running)}",
                       f"mi355_num_requests_waiting {len(eng.sched.waiting)}",
@@ -168,12 +192,18 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
             if not isinstance(body, dict) or not isinstance(body.get("messages"), list) or not body["messages"]:
                 return _error(400, "missing field: messages")
             try:
-                body = dict(body, prompt=render_chat(body["messages"], tokenizer))
+                # a rendered template spells its special tokens out (Llama-3's begins with bos_token):
+                # tokenised without the tokenizer's own post-processor, or the sequence would start
+                # with two BOS ids
+                rendered = render_chat(body["messages"], tokenizer)
+                body = dict(body, prompt=tokenizer.encode(rendered, add_special_tokens=False))
             except (ValueError, TypeError, KeyError) as exc:
                 return _error(400, f"cannot render the messages: {exc}")
+            if not body["prompt"]:
+                return _error(400, "the messages render to an empty prompt")
             if body.get("max_tokens") is None:
                 body["max_tokens"] = body.get("max_completion_tokens") or max(
-                    1, max_model_len - len(tokenizer.encode(body["prompt"])) - 1)
+                    1, max_model_len - len(body["prompt"]) - 1)
             body.pop("echo", None)
             if body.get("logprobs") is True:              # chat form: a boolean + top_logprobs
                 body["logprobs"] = int(body.get("top_logprobs") or 0)
@@ -248,6 +278,11 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
         lp_objs = [{"tokens": [], "token_logprobs": [], "top_logprobs": [], "text_offset": []} if want_lp is not None
                    else None for _ in prompts]
 
+        # return_tokens_as_token_ids: the logprobs object names tokens as "token_id:<id>" instead of by their
+        # text (pieces of a multi-byte character, or two tokens with the same text, are otherwise ambiguous)
+        as_ids = bool(body.get("return_tokens_as_token_ids", False))
+        piece_of = (lambda t: f"token_id:{t}") if as_ids else (lambda t: tokenizer.decode([t]))
+
         def add_logprobs(i: int, o, offset: int) -> Optional[dict]:
             """Appends the step's tokens to choice i's logprobs object; returns the same fields for this step alone."""
             if lp_objs[i] is None or not o.logprobs:
@@ -256,21 +291,21 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
             if getattr(o, "prompt_logprobs", None):           # first output of an echo + logprobs request
                 at = 0
                 for tok, ent in zip(prompts[i], o.prompt_logprobs):
-                    piece = tokenizer.decode([tok])
+                    piece = piece_of(tok)
                     step["tokens"].append(piece)
                     step["token_logprobs"].append(None if ent is None else ent[0])
                     if ent is None or not want_lp:
                         step["top_logprobs"].append(None)
                     else:                                     # the prompt token itself is always listed
-                        top = {tokenizer.decode([t]): v for t, v in ent[1]}
+                        top = {piece_of(t): v for t, v in ent[1]}
                         top.setdefault(piece, ent[0])
                         step["top_logprobs"].append(top)
                     step["text_offset"].append(at)
-                    at += len(piece)
+                    at += len(tokenizer.decode([tok]))
             for tok, (lp, top) in zip(o.new_token_ids, o.logprobs):
-                step["tokens"].append(tokenizer.decode([tok]))
+                step["tokens"].append(piece_of(tok))
                 step["token_logprobs"].append(lp)
-                step["top_logprobs"].append({tokenizer.decode([t]): v for t, v in top} if want_lp else None)
+                step["top_logprobs"].append({piece_of(t): v for t, v in top} if want_lp else None)
                 step["text_offset"].append(offset)
             for k2, v in step.items():
                 lp_objs[i][k2].extend(v)
@@ -285,6 +320,9 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
                     return True
             return False
 
+        # characters a stream holds back while a stop string may still be forming across tokens
+        hold = max((len(s) for s in params.stop), default=1) - 1
+
         async def events():
             done = 0
             sent = [len(t) if not echo else 0 for t in texts]
@@ -296,7 +334,10 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
                     continue
                 n_out[i] = o.num_output_tokens
                 step_lp = add_logprobs(i, o, len(texts[i]))
-                texts[i] += detoks[i].push(o.new_token_ids, final=o.finished)
+                # a sequence the engine ended on a token (end-of-sequence id, stop_token_ids) does not
+                # show that token in its text; it still counts as a completion token
+                shown = o.new_token_ids[:-1] if o.finished and o.finish_reason == "stop" else o.new_token_ids
+                texts[i] += detoks[i].push(shown, final=o.finished)
                 hit = bool(params.stop) and apply_stop(i)
                 if hit:
                     reasons[i] = "stop"
@@ -305,8 +346,9 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
                     reasons[i] = o.finish_reason
                 if reasons[i] is not None:
                     done += 1
-                delta = texts[i][sent[i]:]
-                sent[i] = len(texts[i])
+                upto = len(texts[i]) if reasons[i] is not None else max(len(texts[i]) - hold, sent[i])
+                delta = texts[i][sent[i]:upto]
+                sent[i] = upto
                 yield i, delta, reasons[i], step_lp
 
         # a prompt counts once, however many completions it gets
@@ -406,6 +448,9 @@ def main(argv: Optional[List[str]] = None) -> int:
     served = args.served_model_name or args.model
     max_model_len = args.max_model_len or min(cfg.max_position_embeddings, 8192)
     tokenizer = load_tokenizer(args.model, cfg.vocab_size)
+    # generation also ends on the tokenizer's own end-of-sequence token (tokenizer_config.json)
+    from ...config import merge_eos
+    cfg.eos_token_id = merge_eos(cfg.eos_token_id, getattr(tokenizer, "eos_token_id", None))
     if getattr(tokenizer, "is_fallback", False):
         log.warning("no tokenizer.json under %r: text prompts are mapped byte-wise (token-id prompts are exact)", args.model)
 
@@ -428,7 +473,8 @@ def main(argv: Optional[List[str]] = None) -> int:
         return 1 if thread.failed else 0
 
     import uvicorn
-    app = build_app(thread, served, tokenizer, cfg.vocab_size, max_model_len)
+    app = build_app(thread, served, tokenizer, cfg.vocab_size, max_model_len,
+                    requested_dtype=(args.dtype or "auto"), served_dtype=args.resolved_dtype())
     thread.start()
     config = uvicorn.Config(app, host=ns.host, port=ns.port, log_level="warning", access_log=False)
     server = uvicorn.Server(config)
