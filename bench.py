@@ -131,8 +131,8 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eager", action="store_true", help="debug only: no HIP graphs")
     ap.add_argument("--oneshot-allreduce", action="store_true",
-                    help="N > 1: the hand-written one-shot all-reduce for the decode-sized messages instead of RCCL "
-                         "(same as MI355_ONESHOT_ALLREDUCE=1)")
+                    help="N > 1: force the hand-written one-shot all-reduce for the decode-sized messages under any "
+                         "backend (MI355_ONESHOT_ALLREDUCE=1; under RCCL it is the default, =0 switches it off)")
     ap.add_argument("--segments", type=int, default=5,
                     help="timed regions of exactly --steps steps each; the median one is reported")
     ap.add_argument("--no-served", action="store_true", help="skip the measurement through the HTTP server")
@@ -208,7 +208,7 @@ def time_kernels(engine, batch, ctx_len):
     plans = r._tiled_plan(r.bucket_for(b)) if any(mode.values()) else {}
     tq, gq = plans.get("qkv", (0, 1))
     to, go = plans.get("o", (0, 1))
-    tg, _ = plans.get("gu", (0, 1))
+    tp_one = r.tp_size == 1
     td, gd = plans.get("down", (0, 1))
     T, P, lt = r.tiled, ops.EPI_PARTIAL, r._linear_tiled
     name = {"qkv": "qkv", "o": "o", "gu": "gate_up", "down": "down", "lm_head": "lm_head"}
@@ -216,24 +216,33 @@ def time_kernels(engine, batch, ctx_len):
                    "(linear_tiled_kernel, geometry tiles_per_wg/k_groups) and hipBLASLt through torch.mm: "
                    + ", ".join(f"{name[k]} " + (f"tiled {plans[k][0]}/{plans[k][1]}" if mode[k] else "hipBLASLt")
                                for k in r.KINDS)
-                   + ("; SwiGLU in the gate_up epilogue" if mode["gu"] else ""))
+                   + ("; SwiGLU in the gate_up epilogue" if mode["gu"] and plans["gu"][1] == 1 else ""))
     if getattr(r, "tune_us", None):
         out["tuned_us_tiled_vs_library"] = {name[k]: r.tune_us[(r.bucket_for(b), k)] for k in r.KINDS
                                             if (r.bucket_for(b), k) in r.tune_us}
-    if mode["gu"]:
+    tg, gg = plans.get("gu", (0, 1))
+    if mode["gu"] and gg > 1:      # K split over workgroups: fp32 slabs, the SwiGLU gate from the slabs
+        out["gemm_gate_up"] = timed(lambda i: lt(x, T[i]["gu"], 2 * r.F, partial=r.part_gu, tiles_per_wg=tg, k_groups=gg,
+                                                 epilogue=P), gemm(b, 2 * r.F, r.H, 4 * gg))
+        out["silu_and_mul_slabs"] = timed(lambda i: ops.silu_and_mul_slabs(r.part_gu, gg, act),
+                                          b * r.F * (8 * gg + es))
+    elif mode["gu"]:
         out["gemm_gate_up"] = timed(lambda i: lt(x, T[i]["gu"], 2 * r.F, out=act, tiles_per_wg=tg,
                                                  epilogue=ops.EPI_SILU_MUL),
                                     2 * r.F * r.H * wes + b * r.H * es + b * r.F * es)
     else:
         out["gemm_gate_up"] = timed(lambda i: torch.mm(x, r._rm(i, "gu").t(), out=gu), gemm(b, 2 * r.F, r.H, w_es=es))
         out["silu_and_mul"] = timed(lambda i: ops.silu_and_mul(gu, out=act), 3 * b * r.F * es)
-    # a projection whose output is all-reduced (o under tensor parallelism, down when the MLP is
-    # sharded) stores 16 bits instead of fp32 slabs: time the form the step runs
-    slabs_o = mode["o"] and r.tiled_shapes["o"][2]
-    slabs_dn = mode["down"] and r.tiled_shapes["down"][2]
+    # o / down leave fp32 slabs for the add + norm kernel on one GPU; a projection whose output is
+    # all-reduced (o under tensor parallelism, down when the MLP is sharded) leaves slabs only when K
+    # is split over workgroups (mi355_sum_slabs then forms the 16-bit tensor), else stores 16 bits
+    slabs_o = mode["o"] and (tp_one or go > 1)
+    slabs_dn = mode["down"] and (not r.mlp_sharded or gd > 1)
     if slabs_dn:
         out["gemm_down"] = timed(lambda i: lt(act, T[i]["down"], r.H, partial=r.part_dn, tiles_per_wg=td,
                                               k_groups=gd, epilogue=P), gemm(b, r.H, r.F, 4 * gd))
+        if r.mlp_sharded:
+            out["sum_slabs_down"] = timed(lambda i: ops.sum_slabs(r.part_dn, gd, dn), b * r.H * (4 * gd + es))
     elif mode["down"]:
         out["gemm_down"] = timed(lambda i: lt(act, T[i]["down"], r.H, out=dn, tiles_per_wg=td), gemm(b, r.H, r.F))
     else:
@@ -246,6 +255,8 @@ def time_kernels(engine, batch, ctx_len):
     if slabs_o:
         out["gemm_o"] = timed(lambda i: lt(attn, T[i]["o"], r.H, partial=r.part_o, tiles_per_wg=to,
                                            k_groups=go, epilogue=P), gemm(b, r.H, r.nh * r.d, 4 * go))
+        if not tp_one:
+            out["sum_slabs_o"] = timed(lambda i: ops.sum_slabs(r.part_o, go, o), b * r.H * (4 * go + es))
     elif mode["o"]:
         out["gemm_o"] = timed(lambda i: lt(attn, T[i]["o"], r.H, out=o, tiles_per_wg=to), gemm(b, r.H, r.nh * r.d))
     else:
@@ -258,7 +269,7 @@ def time_kernels(engine, batch, ctx_len):
     ctx_tokens = int(r.ctx[:b].sum().item())              # the device buffers still hold the last step's inputs
     kv_bytes = ctx_tokens * 2 * r.nkv * r.d * es + 2 * b * r.nh * r.d * es
     rope_bytes = b * ((r.nh + r.nkv) * r.d * 2 + r.nkv * r.d + 2 * r.nkv * r.d) * es
-    if slabs_dn:
+    if slabs_dn and not r.mlp_sharded:
         out["fused_add_rms_norm"] = timed(
             lambda i: ops.fused_add_rms_norm_partial(r.part_dn, gd, resid, W[i].post_norm, r.eps, x),
             b * r.H * (4 * gd + 3 * es))
@@ -731,8 +742,12 @@ def main():
     result["degraded"] = {"hip_graphs": bool(r_.use_graphs), "graph_capture_failures": r_.capture_failures,
                           "gemm_tune_failures": r_.tune_failures,
                           "allreduce": ("none (1 GPU)" if tp == 1 else
-                                        "one-shot kernel over IPC-mapped buffers" if r_.oneshot is not None else
-                                        ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal)")),
+                                        "one-shot kernel over IPC-mapped buffers (self-test passed on every rank); "
+                                        "larger messages on " + dist.get_backend() if r_.oneshot is not None else
+                                        ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal)")
+                                        + (" -- the one-shot kernel's set-up or self-test failed, fell back"
+                                           if r_.oneshot_fallbacks else "")),
+                          "oneshot_allreduce_fallbacks": r_.oneshot_fallbacks,
                           "gemm_form": {k: ("tiled" if v else "library") for k, v in r_._mode(batch).items()}}
 
     # what the job really ran on: ranks the process group saw, its backend, every rank's device

@@ -303,6 +303,25 @@ int32_t mi355_silu_and_mul(void* out, const void* x, int64_t x_stride,
                            void* stream);
 
 /*
+ * Consumers of the fp32 partial-sum slabs partial[num_slabs][M][N] of a K-split
+ * mi355_linear_tiled (epilogue 2) for the call sites whose next step needs a 16-bit
+ * tensor.  The slabs are added in slab order, so results do not depend on scheduling.
+ *   mi355_sum_slabs:           y[M, N] = round(sum_s partial[s] + bias)   (bias may be NULL)
+ *     -- the attention-output / down projection of a tensor-parallel rank before its
+ *     all-reduce (--tensor-parallel-size, benchmark-vllm/vllm_templates.py:55)
+ *   mi355_silu_and_mul_slabs:  slabs of a gate_up projection tiled with interleave_halves
+ *     (16-column tiles alternate gate / up): out[M, N/2] =
+ *     round(round(silu(round(sum gate))) * round(sum up)), what epilogue 1 computes
+ * num_slabs 1..8; N a multiple of 8 (SwiGLU: 32); y / out row strides in elements.
+ * Same role as the engine's decode GEMM epilogues (see mi355_linear_tiled).
+ */
+int32_t mi355_sum_slabs(void* y, int64_t y_stride, const float* partial, int32_t num_slabs,
+                        const void* bias, int32_t M, int32_t N, int32_t dtype, void* stream);
+int32_t mi355_silu_and_mul_slabs(void* out, int64_t out_stride, const float* partial,
+                                 int32_t num_slabs, int32_t M, int32_t N, int32_t dtype,
+                                 void* stream);
+
+/*
  * Greedy sampling: out_ids[b] = argmax_v logits[b, v]; lowest index on ties, a
  * NaN counts as the maximum (torch.argmax semantics).  logits may be bf16, fp16
  * or fp32 (logits_dtype); row stride in elements.  Serves requests with
@@ -433,7 +452,10 @@ int32_t mi355_untile_weights_fp8(void* dst, const void* src_tiled, const float* 
                                  int32_t dtype, void* stream);
 
 /*
- * Decode-time linear layer on fragment-tiled weights, M <= 128:
+ * Decode-time linear layer on fragment-tiled weights, M <= 256 (a workgroup covers
+ * up to 128 rows; 129 .. 256 rows -- the step of a tensor-parallel rank that serves
+ * --max-num-seqs 256, benchmark-vllm/models.py:9,11 -- run as two row blocks of one
+ * launch, every geometry of the 65 .. 128-row class, epilogues 0-2):
  * y[M, N] = x[M, K] . W[N, K]^T.  Every weight load is 1 KB of contiguous memory
  * and each wave streams one 16-row tile of W; x is staged through LDS once per
  * workgroup, one K slice at a time.  tiles_per_wg = 4 or 8 tiles (= waves) per
@@ -449,14 +471,15 @@ int32_t mi355_untile_weights_fp8(void* dst, const void* src_tiled, const float* 
  * and so cannot be split across workgroups; 402 / 404: the same with 512-wide slices (the SwiGLU
  * epilogue needs at most 4 waves per tile, and a wave at least 128 columns of the slice).  Built
  * geometries: M <= 32: 4, 8, 104, 108, 302, 304, 308, 402, 404; M <= 64: 8, 104, 108, 208, 210,
- * 212, 214, 216, 302, 304, 402; M <= 128: 8, 210, 212, 214, 216, 302.  k_groups (at most K / slice)
+ * 212, 214, 216, 302, 304, 402; beyond 64 rows: 8, 210, 212, 214, 216, 302.  k_groups (at most K / slice)
  * splits K over workgroups; the slices are dealt to the groups as evenly as they
  * go, K / slice need not be a multiple of k_groups.
  *   epilogue 0: y = round(sum + bias)                       (k_groups == 1)
  *   epilogue 1: weights tiled with interleave_halves; y[M, N/2] =
  *               round(round(silu(round(gate))) * round(up))  (k_groups == 1)
  *   epilogue 2: fp32 partial sums to partial[k_groups][M][N]; the consumers
- *               (mi355_fused_add_rms_norm_partial, mi355_rope_kv_write_partial)
+ *               (mi355_fused_add_rms_norm_partial, mi355_rope_kv_write_partial,
+ *               mi355_sum_slabs, mi355_silu_and_mul_slabs)
  *               add the slabs in order, so results do not depend on scheduling.
  * Same role as mi355_linear_decode (the engine's decode GEMMs, --max-num-seqs,
  * vllm_templates.py:53) with the weight layout chosen for this chip.
@@ -616,7 +639,16 @@ int32_t mi355_linear_tiled_w8a8(void* y, int64_t y_stride, void* partial, const 
  *            max_bytes), summed over the ranks in place.  Every rank must issue the same calls
  *            with the same counts in the same order.  A peer that does not arrive within 2 s
  *            makes the kernel give up and leave data as it was:
+ *   run_slabs  the same, but this rank's message is round(slabs[0] + ... + slabs[num_slabs - 1]):
+ *            fp32 partial sums [num_slabs][count] of a K-split mi355_linear_tiled (epilogue 2),
+ *            added in slab order and rounded once on the way into the peers' buffers -- what
+ *            mi355_sum_slabs followed by run computes, without the launch in between.  `out`
+ *            (count 16-bit elements) receives the sum over the ranks; on a timeout it is left as it was
  *   status   synchronises with the queued work and returns MI355_ERR_LAUNCH if that happened
+ *   status_async  queues a copy of the communicator's error word (0: every wait so far was met;
+ *            1 + r: rank r once failed to arrive) to *host_word (pinned host memory) on the
+ *            stream: a serving loop reads it with the step's other results, no extra
+ *            synchronisation, and stops serving in the step that hit it
  *   destroy  unmaps and frees
  * world <= 8, max_bytes <= 16 MiB.  Larger (prefill-sized) messages belong on RCCL.
  */
@@ -626,7 +658,11 @@ int32_t mi355_allreduce_oneshot_init(void** comm_out, int32_t rank, int32_t worl
 int32_t mi355_allreduce_oneshot_connect(void* comm, const void* all_handles);
 int32_t mi355_allreduce_oneshot_run(void* comm, void* data, int64_t count,
                                     int32_t dtype, void* stream);
+int32_t mi355_allreduce_oneshot_run_slabs(void* comm, void* out, const float* slabs,
+                                          int32_t num_slabs, int64_t count, int32_t dtype,
+                                          void* stream);
 int32_t mi355_allreduce_oneshot_status(void* comm);
+int32_t mi355_allreduce_oneshot_status_async(void* comm, uint32_t* host_word, void* stream);
 int32_t mi355_allreduce_oneshot_destroy(void* comm);
 
 #ifdef __cplusplus

@@ -21,14 +21,21 @@ from mi355_decode.config import ModelConfig  # noqa: E402
 from mi355_decode.model_runner import ModelRunner  # noqa: E402
 
 
-def step_ms(cfg, tp, batch, ctx, shard_mlp, tiled, layers):
+def step_ms(cfg, tp, batch, ctx, shard_mlp, tiled, layers, oneshot=False):
     max_len = ctx + 64
     bps = (max_len + 15) // 16
     ws = W.synthetic(cfg, torch.bfloat16, "cuda", seed=1, tp_rank=tp - 1, tp_size=tp, num_layers=layers,
                      shard_mlp=shard_mlp, shard_vocab=shard_mlp)
     r = ModelRunner(cfg, ws, torch.bfloat16, "cuda", num_blocks=batch * bps, max_num_seqs=batch, max_model_len=max_len,
                     tp_rank=tp - 1, tp_size=tp, tp_group=None, tiled_linears=tiled)
-    r._allreduce = lambda t: None
+    if oneshot:
+        # the rank's own share of the one-shot all-reduce: a communicator of ONE rank (the kernel delivers the
+        # message into its own buffer, waits for its own flag and "sums" one slot) -- launch, slab sum and local
+        # traffic are real, the peers' traffic and arrival skew are not
+        from mi355_decode.collectives import OneShotAllReduce
+        r.oneshot = OneShotAllReduce(rank=0, world=1, max_bytes=max(1 << 20, batch * cfg.hidden_size * 2))
+    else:
+        r._allreduce = lambda t: None
     r._allreduce_max = lambda t: None
     n64, n32 = r.host_inputs()
     B = batch
@@ -51,9 +58,10 @@ def step_ms(cfg, tp, batch, ctx, shard_mlp, tiled, layers):
     ms = s.elapsed_time(e) / 20
     used = "".join(k[0] if v else "-" for k, v in r._mode(B).items())      # q o g d l: projections on tiled kernels
     tuned = {k: v for (_, k), v in getattr(r, "tune_us", {}).items()}
+    plans = {k: list(v) for k, v in r._tiled_plan(r.bucket_for(B)).items()} if r.tiled is not None else {}
     del r, ws
     torch.cuda.empty_cache()
-    return ms, used, tuned
+    return ms, used, tuned, plans
 
 
 def main():
@@ -63,6 +71,9 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--ctx", type=int, default=192)
     ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--oneshot", action="store_true",
+                    help="keep the all-reduce launches: a one-rank communicator of the one-shot kernel (slab sums formed "
+                         "inside it) instead of no-ops")
     a = ap.parse_args()
     cfg = ModelConfig.from_pretrained(a.model)
     L = a.layers or cfg.num_hidden_layers
@@ -70,13 +81,15 @@ def main():
         batch = a.batch_per_gpu * tp
         for shard in (False, True):
             for tiled in (True, False, None):
-                ms, used, tuned = step_ms(cfg, tp, batch, a.ctx, shard, tiled, L)
+                ms, used, tuned, plans = step_ms(cfg, tp, batch, a.ctx, shard, tiled, L, a.oneshot)
                 if tiled is True and used == "-----":
                     continue                              # no tiled kernels for this row count: same as library
                 print(json.dumps({"model": a.model, "tp": tp, "batch": batch, "layers": L, "mlp_and_vocab_sharded": shard,
+                                  "allreduce": "one-rank one-shot kernel" if a.oneshot else "no-op",
                                   "gemms": {True: "tiled", False: "library", None: "timed choice"}[tiled],
                                   "tiled_projections": used, "rank_step_ms": round(ms, 4),
                                   "tok_s_without_collectives": round(batch / ms * 1e3, 1),
+                                  **({"tiled_plans": plans} if used != "-----" else {}),
                                   **({"tuned_us_tiled_vs_library": tuned} if tuned else {})}), flush=True)
 
 

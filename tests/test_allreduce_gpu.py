@@ -1,7 +1,10 @@
-"""One-shot all-reduce (mi355_allreduce_oneshot_*): two ranks -- two processes on the one GPU of
-the test box, their buffers mapped into each other through HIP IPC -- against the sum formed on
+"""One-shot all-reduce (mi355_allreduce_oneshot_*): two and four ranks -- processes on the one GPU
+of the test box, their buffers mapped into each other through HIP IPC -- against the sum formed on
 the host in rank order (fp32, one rounding: what every rank must produce, bit for bit), eagerly
-with changing message sizes and replayed from a HIP graph; and a single rank (sum of one).
+with changing message sizes up to 2 MiB (256 rows of a 4096-wide model), from fp32 slabs (the slab
+sum of a K-split projection formed inside the all-reduce launch) and replayed from a HIP graph; the
+known-answer self-test the engine runs before it relies on the kernel; the error word copied out
+with a step's results; and a single rank (sum of one).
 Not run across xGMI links here: one-GPU boxes only."""
 import multiprocessing as mp
 import os
@@ -16,7 +19,20 @@ torch = pytest.importorskip("torch")
 
 from oracle import ops_ref as R  # noqa: E402
 
-COUNTS = [8, 4096 * 16, 1000 * 8, 4096 * 128, 4096 * 32, 8, 4096 * 128]      # elements; 1 MiB = 4096 * 128 bf16
+COUNTS = [8, 4096 * 16, 1000 * 8, 4096 * 128, 4096 * 256, 4096 * 32, 8, 4096 * 256]      # elements; 2 MiB = 4096 * 256 bf16
+SLAB_CASES = [(2, 4096 * 16), (8, 4096 * 128), (3, 1000 * 8), (4, 4096 * 256)]            # (slabs, elements)
+
+
+def _slabs(rank, i, n, count):
+    rng = np.random.Generator(np.random.PCG64(77000 + 1000 * i + rank))
+    return (rng.standard_normal((n, count)) * (1 + rank)).astype(np.float32)
+
+
+def _slab_sum(s, dtype):
+    acc = np.zeros(s.shape[1], np.float32)
+    for g in range(s.shape[0]):
+        acc = acc + s[g]
+    return R.round_to(acc, dtype)
 
 
 def _inputs(rank, i, count, dtype):
@@ -42,13 +58,22 @@ def _worker(rank, world, conns, dtype, out_q):
             conns[0].send_bytes(mine)
             return conns[0].recv()
 
-        ar = OneShotAllReduce(max_bytes=1 << 20, rank=rank, world=world, exchange=exchange)
+        ar = OneShotAllReduce(max_bytes=1 << 21, rank=rank, world=world, exchange=exchange)
+        assert ar.self_test("cuda"), "the known-answer self-test failed"
         results = []
         for i, count in enumerate(COUNTS):                       # eager calls, sizes changing from call to call
             t = T.from_numpy(_inputs(rank, i, count, dtype)).to(tdt).cuda()
             ar.run(t)
             results.append(t.float().cpu().numpy())
         ar.check()
+        for i, (n, count) in enumerate(SLAB_CASES):              # this rank's message formed from fp32 slabs in the launch
+            sl = T.from_numpy(_slabs(rank, i, n + 1, count)).cuda()          # one slab more than is summed
+            out = T.full((count,), 3.0, dtype=tdt, device="cuda")
+            ar.run_slabs(sl, n, out)
+            results.append(out.float().cpu().numpy())
+        ar.queue_status(1)                                        # the error word, copied out with a step's results
+        T.cuda.synchronize()
+        ar.raise_if_failed(1)
         # the same call replayed from a HIP graph: the round counter advances on the device
         count = 4096 * 32
         buf = T.zeros(count, dtype=tdt, device="cuda")
@@ -71,13 +96,13 @@ def _worker(rank, world, conns, dtype, out_q):
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
-def test_two_ranks_on_one_gpu_match_the_host_sum(dtype):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_on_one_gpu_match_the_host_sum(dtype, world):
     ctx = mp.get_context("spawn")
-    a, b = ctx.Pipe()
+    pipes = [ctx.Pipe() for _ in range(world - 1)]
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(0, world, [a], dtype, q)),
-             ctx.Process(target=_worker, args=(1, world, [b], dtype, q))]
+    procs = [ctx.Process(target=_worker, args=(0, world, [a for a, _ in pipes], dtype, q))] + \
+            [ctx.Process(target=_worker, args=(r, world, [pipes[r - 1][1]], dtype, q)) for r in range(1, world)]
     for p in procs:
         p.start()
     got = {}
@@ -91,11 +116,19 @@ def test_two_ranks_on_one_gpu_match_the_host_sum(dtype):
             p.join(timeout=20)
             if p.is_alive():
                 p.kill()
-    cases = [(i, c) for i, c in enumerate(COUNTS)] + [(100 + k, 4096 * 32) for k in range(3)]
-    for j, (i, count) in enumerate(cases):
-        want = R.round_to(sum(_inputs(r, i, count, dtype).astype(np.float32) for r in range(world)), dtype)
+    def rank_sum(parts):
+        acc = np.zeros_like(parts[0], dtype=np.float32)
+        for part in parts:                                       # rank order, fp32, one rounding
+            acc = acc + part.astype(np.float32)
+        return R.round_to(acc, dtype)
+
+    wants = [rank_sum([_inputs(r, i, c, dtype) for r in range(world)]) for i, c in enumerate(COUNTS)]
+    wants += [rank_sum([_slab_sum(_slabs(r, i, n + 1, c)[:n], dtype) for r in range(world)]) for i, (n, c) in enumerate(SLAB_CASES)]
+    wants += [rank_sum([_inputs(r, 100 + k, 4096 * 32, dtype) for r in range(world)]) for k in range(3)]
+    assert all(len(got[r]) == len(wants) for r in range(world))
+    for j, want in enumerate(wants):
         for r in range(world):
-            np.testing.assert_array_equal(got[r][j], want, err_msg=f"rank {r}, call {j} ({count} elements)")
+            np.testing.assert_array_equal(got[r][j], want, err_msg=f"rank {r}, call {j} ({want.size} elements)")
 
 
 def test_single_rank_is_the_identity_and_sizes_are_checked():
@@ -107,6 +140,13 @@ def test_single_rank_is_the_identity_and_sizes_are_checked():
     ar.run(x)
     ar.check()
     assert torch.equal(x, want)
+    slabs = torch.randn(3, 4096, device="cuda")
+    out = torch.empty(4096, dtype=torch.bfloat16, device="cuda")
+    ar.run_slabs(slabs, 3, out)                                   # one rank: the rounded slab sum itself
+    assert torch.equal(out, ((slabs[0] + slabs[1]) + slabs[2]).to(torch.bfloat16))
+    with pytest.raises(Mi355Error, match="num_slabs"):
+        ar.run_slabs(torch.randn(9, 4096, device="cuda"), 9, out)
+    assert ar.self_test("cuda")
     assert not ar.fits(torch.zeros((1 << 15) + 8, dtype=torch.bfloat16, device="cuda"))   # beyond max_bytes
     assert not ar.fits(torch.zeros(12, dtype=torch.bfloat16, device="cuda"))               # not a multiple of 8
     with pytest.raises(ValueError):

@@ -3,7 +3,7 @@
 rank's weights, KV pages and step inputs (same 16-bit rounding points), on the
 weight-streaming tiled GEMM path and on library GEMMs.  This pins the kernels at the shapes
 the tiny-model oracle tests cannot reach (K = 3584 / 8192 / 28672, GQA groups 7 and 8,
-2304-token contexts with split-KV attention, 128 rows), and a second assertion keeps the two
+2304-token contexts with split-KV attention, 128 and 256 rows), and a second assertion keeps the two
 GEMM paths within the same bound of each other.
 
 configs (BASELINE.json): [1] Llama-3-8B TP1 batch 32; [2] Llama-3-8B TP4 batch 128;
@@ -29,6 +29,8 @@ CASES = [
     ("cfg1", "llama-3-8b", 1, 0, 32, 200, 256, False, False),
     ("cfg2", "llama-3-8b", 4, 2, 128, 200, 256, False, False),
     ("cfg2_mlp_sharded", "llama-3-8b", 4, 2, 128, 200, 256, True, False),
+    # the 8-GPU point of the scaling run (bench.py --gpus 8: batch 32 per GPU): 256 rows on a TP8 rank's slices
+    ("cfg2_tp8_256rows", "llama-3-8b", 8, 3, 256, 200, 256, True, False),
     ("cfg3", "llama-3-70b", 8, 5, 16, 2100, 2304, False, False),
     ("cfg3_mlp_sharded", "llama-3-70b", 8, 5, 16, 2100, 2304, True, False),
     ("cfg4_bf16", "qwen2-7b", 1, 0, 64, 700, 1024, False, False),

@@ -1117,7 +1117,101 @@ def test_linear_tiled_rejects_unbuilt_geometries(ops):
         ops.linear_tiled(x[:, :640].contiguous(), ops.tile_weights(torch.zeros(64, 640, dtype=torch.bfloat16, device="cuda")),
                          64, tiles_per_wg=8)
     with pytest.raises(Mi355Error, match="outside"):
-        ops.linear_tiled(torch.zeros(129, 1024, dtype=torch.bfloat16, device="cuda"), wt, 64)
+        ops.linear_tiled(torch.zeros(257, 1024, dtype=torch.bfloat16, device="cuda"), wt, 64)
+    with pytest.raises(Mi355Error, match="up to 128 rows"):
+        ops.linear_tiled_fused(torch.zeros(129, 1024, dtype=torch.bfloat16, device="cuda"), wt, 64, tiles_per_wg=8, k_groups=2,
+                               epilogue=ops.EPI_REDUCE_STORE, counters=torch.zeros(8, dtype=torch.int32, device="cuda"))
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,N,K,tiles,groups", [(128, 1536, 4096, 8, 4), (192, 1536, 4096, 8, 4), (256, 1536, 4096, 8, 8),
+                                                (129, 320, 512, 8, 1), (256, 4096, 1024, 302, 1), (192, 4096, 3584, 8, 7),
+                                                (256, 7168, 4096, 216, 4), (200, 1544, 4096, 212, 8), (256, 336, 512, 214, 1),
+                                                (256, 4096, 512, 302, 2), (130, 1000, 1024, 210, 2), (256, 16032, 4096, 8, 1)])
+def test_linear_tiled_129_to_256_rows(ops, dtype, M, N, K, tiles, groups):
+    """129 .. 256 rows (the decode step of a tensor-parallel rank that serves 256 sequences): two row
+    blocks of one launch.  Store, partial slabs and both slab consumers against the fp64 product, and
+    every row block bit-identical to the same rows run as a launch of their own."""
+    rng = rng_for("tiled-rowblocks", dtype, M, N, K)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (N, K), dtype, 0.05)
+    wt, xd = ops.tile_weights(dev(w, dtype)), dev(x, dtype)
+    ref64 = x.astype(np.float64) @ w.astype(np.float64).T
+    tol = _linear_tol(ref64, x, w, K, dtype)
+    if groups == 1:
+        yd = ops.linear_tiled(xd, wt, N, tiles_per_wg=tiles)
+        y = host(yd)
+        assert (np.abs(y - ref64) <= tol).all()
+        assert (y != R.linear(x, w, None, dtype)).mean() <= 0.02
+        for a in range(0, M, 128):                                   # a row block computes what a launch of its rows computes
+            if M - a <= 64:                                          # (fewer rows take another geometry: another slice width)
+                continue
+            np.testing.assert_array_equal(host(ops.linear_tiled(xd[a:a + 128].contiguous(), wt, N, tiles_per_wg=tiles)),
+                                          y[a:a + 128])
+        y0 = host(ops.linear_tiled(xd, wt, N))                       # geometry chosen by the wrapper
+        assert (np.abs(y0 - ref64) <= tol).all()
+    partd = ops.linear_tiled(xd, wt, N, k_groups=groups, epilogue=ops.EPI_PARTIAL, tiles_per_wg=tiles)
+    part = partd.cpu().numpy()
+    assert part.shape == (groups, M, N)
+    unit = ops.tiled_slice_width(M, tiles)
+    units = K // unit
+    edges = [unit * (g * (units // groups) + min(g, units % groups)) for g in range(groups + 1)]
+    for g in range(groups):
+        ref = x[:, edges[g]:edges[g + 1]].astype(np.float64) @ w[:, edges[g]:edges[g + 1]].astype(np.float64).T
+        np.testing.assert_allclose(part[g], ref, rtol=1e-4, atol=2e-3)
+    y_ref = _slab_sum(part, None, dtype)
+    assert (np.abs(y_ref - ref64) <= tol).all()
+    if N % 8 == 0:
+        ys = ops.sum_slabs(partd, groups, torch.empty(M, N, dtype=DT[dtype], device="cuda"))
+        np.testing.assert_array_equal(host(ys), y_ref)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,N,S,bias", [(128, 4096, 4, False), (256, 4096, 8, True), (5, 448, 1, True), (33, 1000, 3, False),
+                                        (192, 8192, 2, False), (1, 8, 7, False)])
+def test_sum_slabs(ops, dtype, M, N, S, bias):
+    """Slabs -> the 16-bit tensor an all-reduce takes: the fixed-order fp32 slab sum (+ bias), one rounding; bit-exact
+    against the oracle's slab sum, with a strided destination and slabs beyond num_slabs ignored."""
+    rng = rng_for("sum-slabs", dtype, M, N, S)
+    part = (rng.standard_normal((S + 1, M, N)) * 0.6).astype(np.float32)
+    b = grid(rng, (N,), dtype) if bias else None
+    pd = torch.from_numpy(part).cuda()
+    out = torch.full((M, N + 8), 7.0, dtype=DT[dtype], device="cuda")
+    ops.sum_slabs(pd, S, out[:, :N], dev(b, dtype) if bias else None)      # the slab after the first S is not read
+    ref = _slab_sum(part[:S], b, dtype)
+    np.testing.assert_array_equal(host(out[:, :N]), ref)
+    assert (host(out[:, N:]) == 7.0).all()
+    from mi355_decode._lib import Mi355Error
+    with pytest.raises((Mi355Error, ValueError)):
+        ops.sum_slabs(pd, 9, out[:, :N])
+    with pytest.raises((Mi355Error, ValueError)):
+        ops.sum_slabs(pd.to(torch.float64), S, out[:, :N])
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,F,K,tiles,groups", [(128, 3584, 4096, 8, 4), (256, 1792, 4096, 8, 4), (32, 1536, 1024, 104, 2),
+                                                (64, 512, 1024, 216, 2), (200, 3584, 4096, 302, 2), (7, 64, 2048, 4, 2),
+                                                (128, 3584, 4096, 212, 8)])
+def test_silu_and_mul_slabs(ops, dtype, M, F, K, tiles, groups):
+    """SwiGLU from the slabs of a K-split gate_up projection: bit-identical to the oracle's SwiGLU of the rounded
+    fixed-order slab sums (de-interleaved), and to the GEMM's own SwiGLU epilogue when there is one slab."""
+    rng = rng_for("silu-slabs", dtype, M, F, K)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (2 * F, K), dtype, 0.05)
+    xd = dev(x, dtype)
+    wi = ops.tile_weights(dev(w, dtype), interleave_halves=True)
+    partd = ops.linear_tiled(xd, wi, 2 * F, k_groups=groups, epilogue=ops.EPI_PARTIAL, tiles_per_wg=tiles)
+    act = host(ops.silu_and_mul_slabs(partd, groups, torch.empty(M, F, dtype=DT[dtype], device="cuda")))
+    # slab columns: 16-column tiles alternating gate / up
+    summed = _slab_sum(partd.cpu().numpy(), None, dtype).reshape(M, F // 16, 2, 16)
+    gate_up = np.concatenate([summed[:, :, 0].reshape(M, F), summed[:, :, 1].reshape(M, F)], axis=1)
+    np.testing.assert_array_equal(act, host(ops.silu_and_mul(dev(gate_up, dtype))))     # the SwiGLU kernel's bits
+    assert_ulp_close(act, R.silu_and_mul(gate_up, dtype), dtype, 0.005)                 # ... and the oracle's bar for SwiGLU
+    # against the exact product: SwiGLU of the correctly rounded gate / up values, up to the GEMM's ulp flips
+    ref = R.silu_and_mul(R.linear(x, w, None, dtype), dtype)
+    diff = np.abs(act - ref)
+    assert (diff <= 4 * ULP[dtype] * np.abs(ref) + 4 * ULP[dtype] * 1e-2).all()
+    one = ops.linear_tiled(xd, wi, 2 * F, k_groups=1, epilogue=ops.EPI_PARTIAL, tiles_per_wg=tiles)
+    np.testing.assert_array_equal(host(ops.silu_and_mul_slabs(one, 1, torch.empty(M, F, dtype=DT[dtype], device="cuda"))),
+                                  host(ops.linear_tiled(xd, wi, 2 * F, epilogue=ops.EPI_SILU_MUL, tiles_per_wg=tiles)))
 
 
 # --------------------------------------------------------------------------- #

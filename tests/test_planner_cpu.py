@@ -12,13 +12,14 @@ SHAPES = [  # N, K, split_k: the projections of the benchmark models and of thei
 ]
 KW = {302, 304, 308, 402, 404}        # K split across the waves of a workgroup: up to 32 rows
 BUILT = {16: {4, 8, 104, 108} | KW, 32: {4, 8, 104, 108} | KW,
-         64: {8, 104, 108, 208, 210, 212, 214, 216, 302, 304, 402}, 128: {8, 210, 212, 214, 216, 302}}
+         64: {8, 104, 108, 208, 210, 212, 214, 216, 302, 304, 402}, 128: {8, 210, 212, 214, 216, 302},
+         256: {8, 210, 212, 214, 216, 302}}       # two row blocks of the 128-row geometries
 
 
-@pytest.mark.parametrize("M", [1, 16, 17, 32, 33, 64, 65, 128])
+@pytest.mark.parametrize("M", [1, 16, 17, 32, 33, 64, 65, 128, 129, 192, 256])
 @pytest.mark.parametrize("N,K,split", SHAPES)
 def test_candidates_are_built_geometries(M, N, K, split):
-    cls = 16 if M <= 16 else 32 if M <= 32 else 64 if M <= 64 else 128
+    cls = 16 if M <= 16 else 32 if M <= 32 else 64 if M <= 64 else 128 if M <= 128 else 256
     plan = ops.plan_linear_tiled(N, K, split, M)
     cands = ops.linear_tiled_candidates(N, K, split, M)
     if plan is None:
@@ -50,8 +51,8 @@ def test_narrow_slices_get_the_k_split_across_waves():
 
 
 def test_rows_beyond_the_kernels_have_no_plan():
-    assert ops.plan_linear_tiled(4096, 4096, True, 129) is None
-    assert ops.linear_tiled_candidates(4096, 4096, True, 129) == []
+    assert ops.plan_linear_tiled(4096, 4096, True, 257) is None
+    assert ops.linear_tiled_candidates(4096, 4096, True, 257) == []
     assert ops.plan_linear_tiled(4096, 448, True, 32) is None          # K not a multiple of any slice width
 
 
@@ -64,3 +65,13 @@ def test_slice_widths_and_workgroup_tiles():
     assert ops.tiled_slice_width(64, 210) == 512 and ops.tiled_slice_width(128, 214) == 256
     # 2368 tiles (gate_up of Qwen2-7B): 16 per workgroup fill 148 CUs, 10 per workgroup 237
     assert (210, 1) in ops.linear_tiled_candidates(37888, 3584, False, 64, swiglu=True)
+
+
+def test_row_blocks_count_as_workgroups():
+    """129 .. 256 rows run as two row blocks: the same column blocks fill the chip with half the K split."""
+    t128, g128 = ops.plan_linear_tiled(4096, 3584, True, 128)
+    t256, g256 = ops.plan_linear_tiled(4096, 3584, True, 256)
+    assert t128 == t256 == 8 and g256 < g128
+    assert ops.tiled_slice_width(256, 8) == ops.tiled_slice_width(128, 8) == 256
+    # a tensor-parallel rank's gate_up slice at 128 rows may split K (a SwiGLU-from-slabs kernel follows)
+    assert any(g > 1 for _, g in ops.linear_tiled_candidates(7168, 4096, True, 128, swiglu=True))

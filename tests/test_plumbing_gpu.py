@@ -102,6 +102,15 @@ def test_harness_plumbing_pass(tmp_path, case, tp):
             time.sleep(0.2)
         served = client.wait_ready(tries=30, delay=0.5)
         assert served == args[args.index("--served-model-name") + 1]
+        # what precision is served: the harness's default config asks for float32
+        # (/root/reference/benchmark-vllm/models.py:14), the kernels compute in 16 bits, and the model card says so
+        card = client.http.get(f"http://127.0.0.1:{port}/v1/models").json()["data"][0]
+        asked = args[args.index("--dtype") + 1]
+        assert card["requested_dtype"] == asked and card["dtype"] == ("float16" if asked in ("half", "float16") else "bfloat16")
+        assert card["dtype_downgraded"] == (asked == "float32")
+        if case == "cfg1_opt125m_cpu":
+            assert asked == "float32" and card["dtype_downgraded"] is True
+            assert "mi355_dtype_downgraded 1" in client.http.get(f"http://127.0.0.1:{port}/metrics").text
 
         # the evaluation job: 4 token-id prompts, greedy, streaming
         outs = []

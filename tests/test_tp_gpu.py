@@ -47,13 +47,22 @@ def _worker(rank, world, port, name, dtype, shard_mlp, q, oneshot=False):
         r = eng.runner
         assert r.tp_size == world and r.mlp_sharded == shard_mlp == r.vocab_sharded
         assert r.F * (world if shard_mlp else 1) == cfg["intermediate_size"]
-        calls = [0]
-        inner = r._allreduce
+        calls, nested = [0], [0]
+        inner, inner_slabs = r._allreduce, r._allreduce_slabs
 
         def counted(t):
-            calls[0] += 1
+            if not nested[0]:
+                calls[0] += 1
             inner(t)
-        r._allreduce = counted
+
+        def counted_slabs(partial, num_slabs, out):       # the all-reduce of a K-split projection: one collective too
+            calls[0] += 1
+            nested[0] += 1
+            try:
+                inner_slabs(partial, num_slabs, out)
+            finally:
+                nested[0] -= 1
+        r._allreduce, r._allreduce_slabs = counted, counted_slabs
         toks = engine_generate(eng, make_prompts(name, len(LENGTHS), LENGTHS), GEN)
         steps = eng.stats["decode_steps"] + eng.stats["prefill_steps"]
         per_step = r.L * (2 if shard_mlp else 1)               # a step launched ahead may not be counted yet

@@ -58,10 +58,14 @@ inline int64_t ar_buffer_bytes(int world, int64_t max_bytes) {
   return ar_flags_offset(world, max_bytes) + static_cast<int64_t>(world) * kArMaxBlocks * sizeof(unsigned);
 }
 
+// `slabs` != nullptr: this rank's input is not `data` but round(slabs[0] + slabs[1] + ...), fp32
+// partial sums [num_slabs][count] of a projection whose K was split over workgroups, added in slab
+// order and rounded once -- the 16-bit tensor a separate slab-summing launch would have formed
+// (mi355_sum_slabs), formed here on the way into the peers' buffers; `data` is then output only.
 template <typename T>
 __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
     uint16_t* __restrict__ data, int64_t count, ArPeers peers, int rank, int world, int64_t max_bytes,
-    unsigned* __restrict__ rounds, unsigned* __restrict__ error) {
+    unsigned* __restrict__ rounds, unsigned* __restrict__ error, const float* __restrict__ slabs, int num_slabs) {
   const int b = blockIdx.x, nb = gridDim.x, tid = threadIdx.x;
   // the call's round: one more than the last completed call's (nobody advances the word before
   // every workgroup of this call has finished, hence read it)
@@ -75,9 +79,22 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
   const uint4* src = reinterpret_cast<const uint4*>(data);
 
   // 1. deliver this rank's chunk to every rank (own buffer included: the sum below reads all slots alike)
-  for (int p = 0; p < world; ++p) {
-    uint4* dst = reinterpret_cast<uint4*>(peers.buf[p] + (static_cast<int64_t>(parity) * world + rank) * slot_bytes);
-    for (int64_t v = v0 + tid; v < v1; v += kArThreads) dst[v] = src[v];
+  const int64_t slot_off = (static_cast<int64_t>(parity) * world + rank) * slot_bytes;
+  for (int64_t v = v0 + tid; v < v1; v += kArThreads) {
+    uint4 mine_v;
+    if (slabs != nullptr) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < num_slabs; ++g) {
+        const float4* sp = reinterpret_cast<const float4*>(slabs + g * count + 8 * v);
+        const float4 a = sp[0], b = sp[1];
+        acc[0] += a.x, acc[1] += a.y, acc[2] += a.z, acc[3] += a.w;
+        acc[4] += b.x, acc[5] += b.y, acc[6] += b.z, acc[7] += b.w;
+      }
+      mine_v = pack8<T>(acc);
+    } else {
+      mine_v = src[v];
+    }
+    for (int p = 0; p < world; ++p) reinterpret_cast<uint4*>(peers.buf[p] + slot_off)[v] = mine_v;
   }
   // 2. stores first, then the flag: release at system scope, by every thread that stored
   __threadfence_system();
@@ -194,9 +211,9 @@ extern "C" int32_t mi355_allreduce_oneshot_connect(void* comm, const void* all_h
   return MI355_OK;
 }
 
-extern "C" int32_t mi355_allreduce_oneshot_run(void* comm, void* data, int64_t count, int32_t dtype, void* stream) {
+static int32_t allreduce_oneshot_launch(const char* name, void* comm, void* data, const float* slabs, int32_t num_slabs,
+                                        int64_t count, int32_t dtype, void* stream) {
   using namespace mi355;
-  const char* name = "mi355_allreduce_oneshot_run";
   MI355_REQUIRE(comm && data, MI355_ERR_INVALID, "%s: null pointer", name);
   ArComm* c = static_cast<ArComm*>(comm);
   MI355_REQUIRE(c->connected, MI355_ERR_INVALID, "%s: not connected (exchange the handles first)", name);
@@ -205,6 +222,8 @@ extern "C" int32_t mi355_allreduce_oneshot_run(void* comm, void* data, int64_t c
   MI355_REQUIRE(count >= 0 && count % 8 == 0 && count * 2 <= c->max_bytes && aligned16(data), MI355_ERR_INVALID,
                 "%s: count %lld must be a multiple of 8 with count * 2 <= max_bytes %lld, data 16-byte aligned", name,
                 (long long)count, (long long)c->max_bytes);
+  MI355_REQUIRE(slabs == nullptr || (num_slabs >= 1 && num_slabs <= 8 && aligned16(slabs)), MI355_ERR_INVALID,
+                "%s: num_slabs %d outside [1, 8] or slabs not 16-byte aligned", name, num_slabs);
   if (count == 0) return MI355_OK;
   ArPeers peers;
   for (int p = 0; p < kArMaxWorld; ++p) peers.buf[p] = c->peer[p < c->world ? p : c->rank];
@@ -214,11 +233,33 @@ extern "C" int32_t mi355_allreduce_oneshot_run(void* comm, void* data, int64_t c
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == MI355_BF16)
     hipLaunchKernelGGL((allreduce_oneshot_kernel<BF16>), dim3(nb), dim3(kArThreads), 0, s, static_cast<uint16_t*>(data),
-                       count, peers, c->rank, c->world, c->max_bytes, c->rounds, c->error);
+                       count, peers, c->rank, c->world, c->max_bytes, c->rounds, c->error, slabs, num_slabs);
   else
     hipLaunchKernelGGL((allreduce_oneshot_kernel<F16>), dim3(nb), dim3(kArThreads), 0, s, static_cast<uint16_t*>(data),
-                       count, peers, c->rank, c->world, c->max_bytes, c->rounds, c->error);
+                       count, peers, c->rank, c->world, c->max_bytes, c->rounds, c->error, slabs, num_slabs);
   return check_launch(name);
+}
+
+extern "C" int32_t mi355_allreduce_oneshot_run(void* comm, void* data, int64_t count, int32_t dtype, void* stream) {
+  return allreduce_oneshot_launch("mi355_allreduce_oneshot_run", comm, data, nullptr, 0, count, dtype, stream);
+}
+
+extern "C" int32_t mi355_allreduce_oneshot_run_slabs(void* comm, void* out, const float* slabs, int32_t num_slabs,
+                                                     int64_t count, int32_t dtype, void* stream) {
+  using namespace mi355;
+  const char* name = "mi355_allreduce_oneshot_run_slabs";
+  MI355_REQUIRE(slabs != nullptr, MI355_ERR_INVALID, "%s: null pointer", name);
+  return allreduce_oneshot_launch(name, comm, out, slabs, num_slabs, count, dtype, stream);
+}
+
+extern "C" int32_t mi355_allreduce_oneshot_status_async(void* comm, uint32_t* host_word, void* stream) {
+  using namespace mi355;
+  const char* name = "mi355_allreduce_oneshot_status_async";
+  MI355_REQUIRE(comm && host_word, MI355_ERR_INVALID, "%s: null pointer", name);
+  ArComm* c = static_cast<ArComm*>(comm);
+  const hipError_t e = hipMemcpyAsync(host_word, c->error, sizeof(uint32_t), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream));
+  MI355_REQUIRE(e == hipSuccess, MI355_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
+  return MI355_OK;
 }
 
 extern "C" int32_t mi355_allreduce_oneshot_status(void* comm) {

@@ -1,4 +1,5 @@
-// Decode-time linear layer on FRAGMENT-TILED weights:  y[M, N] = x[M, K] . W[N, K]^T, M <= 128.
+// Decode-time linear layer on FRAGMENT-TILED weights:  y[M, N] = x[M, K] . W[N, K]^T, M <= 256
+// (a workgroup covers up to 128 rows; 129 .. 256 rows run as two row blocks of one launch).
 //
 // Weight layout (built once at load time, mi355_tile_weights): W is cut into
 // blocks of 16 rows x 32 k; block (tile, kstep) is 1 KB stored as
@@ -44,6 +45,7 @@
 namespace mi355 {
 
 constexpr int kTU = 4;  // k-steps per register group
+constexpr int kMaxRows = 256;  // rows of x a launch takes: one or two row blocks of up to 128
 
 enum { EPI_STORE = 0, EPI_SILU_MUL = 1, EPI_PARTIAL = 2, EPI_REDUCE_STORE = 3, EPI_REDUCE_RESID = 4 };
 
@@ -60,6 +62,21 @@ struct FusedArgs {
   unsigned* counters;        // EPI_REDUCE_*: [gridDim.x], zero before the first launch, left zero
   const float* w_scale;      // W8: [tiles * 16] fp32, one scale per weight row in tiled row order
 };
+
+// Row blocks (gridDim.z): a launch covers more rows than a workgroup's ROWS (129 .. 256 rows of a
+// wide decode batch) by giving workgroup (.., .., z) rows [z * ROWS, z * ROWS + ROWS): x, y and the
+// slab rows move to the block's first row, M becomes the rows of this block, M_all stays the slab
+// pitch.  The row blocks of a column block stream the same weights at the same time; the second
+// read is served by the caches.
+#define MI355_ROW_BLOCK()                                                   \
+  const int M_all = M;                                                      \
+  {                                                                         \
+    const int m0 = static_cast<int>(blockIdx.z) * ROWS;                     \
+    x += static_cast<int64_t>(m0) * x_stride;                               \
+    if (y != nullptr) y += static_cast<int64_t>(m0) * y_stride;             \
+    if (partial != nullptr) partial += static_cast<int64_t>(m0) * N;        \
+    M = min(M - m0, ROWS);                                                  \
+  }
 
 template <typename T, int MT, int NW, int KSL, int EPI, bool NORM, bool W8 = false>
 __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
@@ -93,6 +110,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   const int kgroup = blockIdx.y;
   // K range of this workgroup: the slices are dealt to the K groups as evenly as they go, the
   // first `rem` groups taking one more -- any group count up to the slice count works
+  MI355_ROW_BLOCK();
 
   // ---- x slice staging: 16-byte vectors, whole rows, coalesced
   constexpr int NX = ROWS * (KSL / 8) / NT;
@@ -297,7 +315,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
       for (int m = 0; m < MT; ++m) {
         const int mm = 16 * m + c;
         if (mm >= M) continue;
-        float* pp = partial + (static_cast<int64_t>(kgroup) * M + mm) * N + n0;
+        float* pp = partial + (static_cast<int64_t>(kgroup) * M_all + mm) * N + n0;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (n0 + r < N && MI355_OK_AT(partial, pp + r, 4))
@@ -337,7 +355,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
       float ss = 0.f;
       if (on) {
         for (int s = 0; s < kgs; ++s) {
-          const float* p = partial + (static_cast<int64_t>(s) * M + row) * N + col;
+          const float* p = partial + (static_cast<int64_t>(s) * M_all + row) * N + col;
           float v[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j)
@@ -385,7 +403,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
     const int mm = 16 * m + c;
     if (mm >= M) continue;
     if (EPI == EPI_PARTIAL) {
-      float* pp = partial + (static_cast<int64_t>(kgroup) * M + mm) * N + n0;
+      float* pp = partial + (static_cast<int64_t>(kgroup) * M_all + mm) * N + n0;
       if (n0 + 3 < N && (N & 3) == 0) {
         MI355_ST(float4, partial, pp, make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]));
       } else {
@@ -444,6 +462,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled2_kernel(
   // both tiles clamped into the matrix; an odd tile count leaves the last wave's second tile a copy (never stored)
   const int tile0 = min(tile_raw, tiles_total - 1), tile1 = min(tile_raw + 1, tiles_total - 1);
   const int kgroup = blockIdx.y;
+  MI355_ROW_BLOCK();
 
   // 5..7 waves do not divide the slice's 16-byte vectors evenly: the last round's surplus threads
   // repeat the slice's last vector (the same bytes to the same LDS address)
@@ -604,7 +623,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled2_kernel(
       const int mm = 16 * m + c;
       if (mm >= M) continue;
       if (EPI == EPI_PARTIAL) {
-        float* pp = partial + (static_cast<int64_t>(kgroup) * M + mm) * N + n0;
+        float* pp = partial + (static_cast<int64_t>(kgroup) * M_all + mm) * N + n0;
         if (n0 + 3 < N && (N & 3) == 0) {
           MI355_ST(float4, partial, pp, make_float4(acc[j][m][0], acc[j][m][1], acc[j][m][2], acc[j][m][3]));
         } else {
@@ -667,6 +686,7 @@ __global__ __launch_bounds__(512) void linear_tiled_kw_kernel(
   const int tile_raw = blockIdx.x * TPG + tl;
   const int tile = min(tile_raw, tiles_total - 1);
   const int kgroup = blockIdx.y;
+  MI355_ROW_BLOCK();
 
   constexpr int NX = ROWS * (KSL / 8) / NT;
   typedef unsigned int xvec __attribute__((ext_vector_type(4)));
@@ -808,7 +828,7 @@ __global__ __launch_bounds__(512) void linear_tiled_kw_kernel(
     const int mm = 16 * m + c;
     if (mm >= M) continue;
     if (EPI == EPI_PARTIAL) {
-      float* pp = partial + (static_cast<int64_t>(kgroup) * M + mm) * N + n0;
+      float* pp = partial + (static_cast<int64_t>(kgroup) * M_all + mm) * N + n0;
       if (n0 + 3 < N && (N & 3) == 0) {
         MI355_ST(float4, partial, pp, make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]));
       } else {
@@ -1112,7 +1132,9 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
   const bool norm = fa.norm_w != nullptr;
   const bool reduce = epilogue == EPI_REDUCE_STORE || epilogue == EPI_REDUCE_RESID;
   MI355_REQUIRE(x && w_tiled, MI355_ERR_INVALID, "%s: null pointer", name);
-  MI355_REQUIRE(M >= 0 && M <= 128, MI355_ERR_UNSUPPORTED, "%s: M %d outside [0, 128]", name, M);
+  MI355_REQUIRE(M >= 0 && M <= kMaxRows, MI355_ERR_UNSUPPORTED, "%s: M %d outside [0, %d]", name, M, kMaxRows);
+  MI355_REQUIRE(M <= 128 || (!norm && !reduce), MI355_ERR_UNSUPPORTED,
+                "%s: the norm prologue and the in-launch reduction are built for up to 128 rows (M %d)", name, M);
   MI355_REQUIRE(epilogue >= EPI_STORE && epilogue <= EPI_REDUCE_RESID, MI355_ERR_INVALID, "%s: unknown epilogue %d",
                 name, epilogue);
   // tiles_per_wg: 4 or 8 tiles (= waves) per workgroup; +100 selects the narrow x slice.  The slice is
@@ -1127,7 +1149,7 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
   const int nw = two ? (tiles_per_wg - 200) / 2 : tiles_per_wg % 100;
   MI355_REQUIRE(two || kws || ((nw == 4 || nw == 8) && (tiles_per_wg == nw || tiles_per_wg == nw + 100)),
                 MI355_ERR_INVALID, "%s: tiles_per_wg must be 4, 8, 104, 108, 208-216 (even), 302, 304, 308, 402 or 404", name);
-  const int mt = M <= 16 ? 1 : M <= 32 ? 2 : M <= 64 ? 4 : 8;
+  const int mt = M <= 16 ? 1 : M <= 32 ? 2 : M <= 64 ? 4 : 8;   // beyond 128 rows: row blocks of 128 (gridDim.z)
   const int ksl = ((kws ? tiles_per_wg >= 400 : two ? tiles_per_wg == 208 : tiles_per_wg >= 100) ? 512 : 1024) /
                   (mt <= 2 ? 1 : mt / 2);
   MI355_REQUIRE(!kws || (!norm && !reduce && fa.w_scale == nullptr), MI355_ERR_UNSUPPORTED,
@@ -1139,7 +1161,7 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
   MI355_REQUIRE(!kws || epilogue != EPI_SILU_MUL || tiles_per_wg % 100 <= 4, MI355_ERR_UNSUPPORTED,
                 "%s: the SwiGLU epilogue needs the gate and up tiles in one workgroup: at most 4 waves per tile", name);
   MI355_REQUIRE(!two || (M > 32 && !norm && !reduce), MI355_ERR_UNSUPPORTED,
-                "%s: two tiles per wave (tiles_per_wg %d) is built for 33..128 rows and epilogues 0-2", name, tiles_per_wg);
+                "%s: two tiles per wave (tiles_per_wg %d) is built for 33 rows and more and epilogues 0-2", name, tiles_per_wg);
   MI355_REQUIRE(N > 0 && K > 0 && K % ksl == 0, MI355_ERR_UNSUPPORTED,
                 "%s: K %d must be a multiple of the x slice %d (M %d)", name, K, ksl, M);
   MI355_REQUIRE(fa.w_scale == nullptr || (aligned16(fa.w_scale) && epilogue <= EPI_PARTIAL), MI355_ERR_INVALID,
@@ -1180,7 +1202,7 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
   if (M == 0) return MI355_OK;
   const int tiles_total = (N + 15) / 16;
   const int tiles_wg = kws ? 8 / (tiles_per_wg % 100) : two ? 2 * nw : nw;
-  dim3 grid((tiles_total + tiles_wg - 1) / tiles_wg, k_groups);
+  dim3 grid((tiles_total + tiles_wg - 1) / tiles_wg, k_groups, (M + 127) / 128);
   hipStream_t s = static_cast<hipStream_t>(stream);
   auto* yp = static_cast<uint16_t*>(y);
   auto* xp = static_cast<const uint16_t*>(x);
@@ -1204,7 +1226,7 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
                                                     x_stride, y_stride, tiles_total, phases, fa);
   MI355_REQUIRE(ok, MI355_ERR_UNSUPPORTED,
                 "%s: no kernel for M %d with tiles_per_wg %d, epilogue %d%s (M <= 32: 4/8/104/108/302/304/308/402/404, "
-                "fused and fp8 forms 8/104; M <= 64: 8/104/108/208-216/302/304/402; M <= 128: 8/210-216/302)", name, M,
+                "fused and fp8 forms 8/104; M <= 64: 8/104/108/208-216/302/304/402; beyond: 8/210-216/302)", name, M,
                 tiles_per_wg, epilogue,
                 norm ? " + norm prologue" : "");
   return check_launch(name);

@@ -51,6 +51,8 @@ def _load() -> ctypes.CDLL:
         "mi355_paged_attn_prefill": (I32, [P, I64, P, I64, P, P, I32, P, I32, P, P, I32, I32, I32, I32, I32,
                                            F, I32, P]),
         "mi355_silu_and_mul": (I32, [P, P, I64, I64, I32, I32, P]),
+        "mi355_sum_slabs": (I32, [P, I64, P, I32, P, I32, I32, I32, P]),
+        "mi355_silu_and_mul_slabs": (I32, [P, I64, P, I32, I32, I32, I32, P]),
         "mi355_argmax": (I32, [P, P, I64, I32, I32, I32, P]),
         "mi355_argmax_chunked": (I32, [P, P, P, P, I64, I32, I32, I32, P]),
         "mi355_embed_rms_norm": (I32, [P, P, P, P, I64, P, I64, I32, I64, I64, I64, F, I32, P]),
@@ -84,7 +86,9 @@ def _load() -> ctypes.CDLL:
         "mi355_allreduce_oneshot_init": (I32, [P, I32, I32, I64, P]),
         "mi355_allreduce_oneshot_connect": (I32, [P, P]),
         "mi355_allreduce_oneshot_run": (I32, [P, P, I64, I32, P]),
+        "mi355_allreduce_oneshot_run_slabs": (I32, [P, P, P, I32, I64, I32, P]),
         "mi355_allreduce_oneshot_status": (I32, [P]),
+        "mi355_allreduce_oneshot_status_async": (I32, [P, P, P]),
         "mi355_allreduce_oneshot_destroy": (I32, [P]),
         "mi355_linear_decode": (I32, [P, I64, P, I64, P, P, I32, I32, I32, I32, I32, P]),
     }
@@ -101,7 +105,7 @@ lib = _load()
 EXPORTS = ("mi355_abi_version", "mi355_last_error", "mi355_target_arch",
            "mi355_bounds_enabled", "mi355_bounds_set_ranges", "mi355_bounds_report", "mi355_rms_norm",
            "mi355_fused_add_rms_norm", "mi355_rope_kv_write", "mi355_paged_attn_decode_workspace",
-           "mi355_paged_attn_decode", "mi355_paged_attn_decode_static", "mi355_paged_attn_prefill", "mi355_silu_and_mul", "mi355_argmax",
+           "mi355_paged_attn_decode", "mi355_paged_attn_decode_static", "mi355_paged_attn_prefill", "mi355_silu_and_mul", "mi355_sum_slabs", "mi355_silu_and_mul_slabs", "mi355_argmax",
            "mi355_argmax_chunked", "mi355_embed_rms_norm",
            "mi355_layer_norm", "mi355_fused_add_layer_norm", "mi355_embed_pos_layer_norm", "mi355_relu",
            "mi355_argmax_shard_key", "mi355_argmax_key_to_index",
@@ -114,7 +118,8 @@ EXPORTS = ("mi355_abi_version", "mi355_last_error", "mi355_target_arch",
            "mi355_quant_rows_fp8", "mi355_linear_tiled_w8a8",
            "mi355_token_logprobs",
            "mi355_allreduce_oneshot_handle_bytes", "mi355_allreduce_oneshot_init", "mi355_allreduce_oneshot_connect",
-           "mi355_allreduce_oneshot_run", "mi355_allreduce_oneshot_status", "mi355_allreduce_oneshot_destroy")
+           "mi355_allreduce_oneshot_run", "mi355_allreduce_oneshot_run_slabs", "mi355_allreduce_oneshot_status",
+           "mi355_allreduce_oneshot_status_async", "mi355_allreduce_oneshot_destroy")
 
 
 def check(status: int) -> None:

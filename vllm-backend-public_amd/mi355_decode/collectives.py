@@ -1,20 +1,31 @@
 """Host side of the one-shot all-reduce (csrc/allreduce_oneshot.hip): buffer set-up, the exchange
-of the IPC handles over an existing torch.distributed group, and the per-call wrapper.
+of the IPC handles over an existing torch.distributed group, a self-test that every rank must pass
+before the engine relies on it, and the per-call wrappers.
 
-    ar = OneShotAllReduce(group, max_bytes=1 << 20)     # every rank, same arguments
+    ar = OneShotAllReduce(group, max_bytes=1 << 21)     # every rank, same arguments
     ar.run(t)                                            # in place, on the current stream
+    ar.run_slabs(slabs, n, out)                          # out = sum over ranks of round(sum of n fp32 slabs)
     ar.check()                                           # raises if a peer never arrived
 
-Opt-in for the serving engine (MI355_ONESHOT_ALLREDUCE=1): it has run with two ranks on one GPU
-(tests/test_tp_gpu.py), not yet across xGMI links."""
+The engine uses it for the decode-sized messages of a tensor-parallel step whenever RCCL is the
+process group's backend (MI355_ONESHOT_ALLREDUCE=0 keeps RCCL for everything, =1 forces it under
+any backend) -- the harness switches the stock engine's custom all-reduce off
+(benchmark-vllm/vllm_templates.py:62,157-160), so this collective is the engine's own.  It has run
+with several ranks on ONE GPU; across xGMI links it is unmeasured, which is why `connect_or_none`
+maps the peers' buffers, runs a known-answer all-reduce through them on every rank, lets the ranks
+agree on the outcome over the process group, and hands back None -- RCCL stays in charge -- if any
+rank could not map a buffer or saw a wrong sum."""
 from __future__ import annotations
 
 import ctypes
+import logging
 
 import torch
 
-from ._lib import check, lib
+from ._lib import Mi355Error, check, lib
 from .ops import _DT, _stream
+
+log = logging.getLogger("mi355_decode")
 
 
 class OneShotAllReduce:
@@ -26,6 +37,7 @@ class OneShotAllReduce:
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.max_bytes = int(max_bytes)
+        self._comm = None
         n = int(lib.mi355_allreduce_oneshot_handle_bytes())
         handle = ctypes.create_string_buffer(n)
         comm = ctypes.c_void_p()
@@ -43,6 +55,8 @@ class OneShotAllReduce:
         if len(blob) != n * self.world:
             raise RuntimeError("IPC handle exchange returned the wrong number of bytes")
         check(lib.mi355_allreduce_oneshot_connect(self._comm, blob))
+        # the error word of the step in flight lands here (pinned), next to the step's sampled tokens
+        self.host_word = torch.zeros(2, dtype=torch.int32).pin_memory()
 
     def fits(self, t: torch.Tensor) -> bool:
         return (t.is_cuda and t.dtype in (torch.bfloat16, torch.float16) and t.is_contiguous()
@@ -55,8 +69,56 @@ class OneShotAllReduce:
         check(lib.mi355_allreduce_oneshot_run(self._comm, t.data_ptr(), t.numel(), _DT[t.dtype], _stream()))
         return t
 
+    def run_slabs(self, slabs: torch.Tensor, num_slabs: int, out: torch.Tensor) -> torch.Tensor:
+        """out = sum over the ranks of round(slabs[0] + ... + slabs[num_slabs - 1]): the slab sum of a K-split
+        projection formed inside the all-reduce launch (slabs: fp32, [num_slabs, out.numel()] contiguous)."""
+        if not self.fits(out):
+            raise ValueError("one-shot all-reduce takes a contiguous bf16/fp16 GPU tensor of a multiple of 8 elements "
+                             f"and at most {self.max_bytes} bytes")
+        if (slabs.dtype != torch.float32 or not slabs.is_cuda or not slabs.is_contiguous() or num_slabs < 1
+                or slabs.numel() < num_slabs * out.numel()):
+            raise ValueError("slabs must be contiguous float32 holding [num_slabs, out.numel()]")
+        check(lib.mi355_allreduce_oneshot_run_slabs(self._comm, out.data_ptr(), slabs.data_ptr(), num_slabs, out.numel(),
+                                                    _DT[out.dtype], _stream()))
+        return out
+
     def check(self) -> None:
+        """Synchronises with the queued work; raises if a wait of any call so far timed out."""
         check(lib.mi355_allreduce_oneshot_status(self._comm))
+
+    def queue_status(self, slot: int = 0) -> None:
+        """Queues a copy of the error word into host_word[slot] on the current stream (no synchronisation)."""
+        check(lib.mi355_allreduce_oneshot_status_async(self._comm, self.host_word.data_ptr() + 4 * slot, _stream()))
+
+    def raise_if_failed(self, slot: int = 0) -> None:
+        """After the stream work behind queue_status(slot) has completed: raises if a peer failed to arrive."""
+        word = int(self.host_word[slot])
+        if word != 0:
+            raise Mi355Error(f"one-shot all-reduce: rank {self.rank} waited 2 s for rank {word - 1}, which never delivered "
+                             "its chunk; this rank's activations were not reduced -- stopping instead of serving them")
+
+    def self_test(self, device) -> bool:
+        """A known-answer all-reduce through the mapped buffers, at two sizes and on both slot parities,
+        plain and from slabs.  True if this rank saw the exact sums and no wait timed out."""
+        try:
+            ok = True
+            for count in (8 * self.world, min(self.max_bytes // 2, 1 << 19)):
+                count -= count % 8
+                for _ in range(2):                               # both parities
+                    t = torch.full((count,), float(self.rank + 1), dtype=torch.bfloat16, device=device)
+                    t[::3] = 0.5 * (self.rank + 1)
+                    self.run(t)
+                    want = self.world * (self.world + 1) / 2.0
+                    ok &= bool((t[1::3] == want).all().item()) and bool((t[::3] == 0.5 * want).all().item())
+                    s = torch.full((2, count), 0.25 * (self.rank + 1), dtype=torch.float32, device=device)
+                    out = torch.zeros(count, dtype=torch.bfloat16, device=device)
+                    self.run_slabs(s, 2, out)
+                    ok &= bool((out == 0.5 * want).all().item())
+            self.check()
+            return ok
+        except Mi355Error as exc:
+            log.warning("one-shot all-reduce self-test failed on rank %d: %s", self.rank, exc)
+            return False
 
     def close(self) -> None:
         if self._comm is not None:
@@ -68,3 +130,31 @@ class OneShotAllReduce:
             self.close()
         except Exception:
             pass
+
+
+def connect_or_none(group, max_bytes: int, device):
+    """The communicator for `group` if EVERY rank could map every peer's buffer and passed the
+    self-test; else None on every rank (the caller keeps the process group's all-reduce).  The
+    ranks agree on the outcome with a MIN all-reduce over the group, so either all use the one-shot
+    kernel or none does."""
+    import torch.distributed as dist
+    ar, ok = None, 0
+    try:
+        ar = OneShotAllReduce(group, max_bytes=max_bytes)
+        connected = 1
+    except (Mi355Error, RuntimeError) as exc:
+        log.warning("one-shot all-reduce: set-up failed on rank %d (%s)", dist.get_rank(group), exc)
+        connected = 0
+    # everyone must have mapped everything before anyone launches into a peer's buffer
+    flag = torch.tensor([connected], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 1:
+        ok = int(ar.self_test(device))
+        flag.fill_(ok)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ok = int(flag.item())
+    if ok != 1:
+        if ar is not None:
+            ar.close()
+        return None
+    return ar

@@ -135,13 +135,25 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
     runner = runner_cls(cfg, weights, dtype, device, num_blocks, args.max_num_seqs, max_model_len,
                          tp_rank=rank, tp_size=tp, tp_group=group, use_graphs=graphs,
                          decode_splits=decode_splits, weight_fp8=(args.quantization or "").lower() == "fp8", **extra)
-    if tp > 1 and os.environ.get("MI355_ONESHOT_ALLREDUCE", "0") == "1":
-        # opt-in: the hand-written one-shot all-reduce for decode-sized messages (run with two ranks on
-        # one GPU so far, not across xGMI links); larger messages stay on the process group
-        from .collectives import OneShotAllReduce
+    # The decode-sized all-reduces of a tensor-parallel step (64-160 per step, each latency-bound) take
+    # the hand-written one-shot kernel over peer-mapped buffers when the process group is RCCL
+    # (MI355_ONESHOT_ALLREDUCE=0: RCCL for everything; =1: also under another backend, the one-GPU
+    # rehearsals).  Every rank maps the peers' buffers and runs a known-answer all-reduce through
+    # them first; if any rank fails either, all of them stay on the process group -- counted in
+    # runner.oneshot_fallbacks (/metrics, the bench line's degraded.allreduce).
+    want = os.environ.get("MI355_ONESHOT_ALLREDUCE", "auto")
+    if tp > 1 and (want == "1" or (want != "0" and torch.distributed.get_backend(group) == "nccl")):
+        from .collectives import connect_or_none
         rows = max(args.max_num_seqs, 16)
-        runner.oneshot = OneShotAllReduce(group, max_bytes=min(max(1 << 20, rows * cfg.hidden_size * 2), 16 << 20))
-        log.info("rank %d: one-shot all-reduce for messages up to %d bytes", rank, runner.oneshot.max_bytes)
+        max_bytes = min(max(1 << 20, rows * cfg.hidden_size * 2), 16 << 20)
+        runner.oneshot = connect_or_none(group, max_bytes, device)
+        if runner.oneshot is None:
+            runner.oneshot_fallbacks += 1
+            log.warning("rank %d: one-shot all-reduce unavailable (buffer mapping or self-test failed on some rank); "
+                        "using the process group's all-reduce", rank)
+        else:
+            log.info("rank %d: one-shot all-reduce for messages up to %d bytes (self-test passed on all %d ranks)",
+                     rank, runner.oneshot.max_bytes, tp)
     if os.environ.get("MI355_LAZY_TUNE", "0") != "1":
         runner.warm_up()                              # every rank, same order: the choices are broadcast
     log.info("tensor-parallel rank %d of %d on %s: %d layers, MLP %s, lm_head %s, %d KV pages, HIP graphs %s, %s",

@@ -106,6 +106,8 @@ class ModelRunner:
         self._device_collectives = None               # decided at the first collective (see _collective)
         self.oneshot = None                           # collectives.OneShotAllReduce, set by build_engine (opt-in)
         self.oneshot_calls = 0
+        self.oneshot_fallbacks = 0                    # set-ups that ended on the process group's all-reduce instead
+        self._no_collectives = False                  # True while GEMM forms are timed (tune)
         self.decode_splits = decode_splits
         self.weight_fp8 = bool(weight_fp8)
         # keep only the fragment-tiled copy of every decode weight (see _init_tiled / _rm)
@@ -182,6 +184,7 @@ class ModelRunner:
 
     # ------------------------------------------------------------------ #
     KINDS = ("qkv", "o", "gu", "down", "lm_head")
+    ROW_CLASSES = (16, 32, 64, 128, 256)              # row counts the tiled kernels are instantiated for
     # the fused attention kernel sums up to 4 slabs of the qkv projection with straight-line loads
     # (more would not fit its registers); deeper K splits of qkv would take its slow generic prologue
     QKV_MAX_SLABS = 4
@@ -214,13 +217,15 @@ class ModelRunner:
         self.tiled_shapes = {}
         if self.tiled_policy == "off" or self.dtype not in (torch.bfloat16, torch.float16) or (2 * self.F) % 32:
             return
-        self.tiled_shapes = {"qkv": (self.qw, self.H, True), "gu": (2 * self.F, self.H, False),
-                             "lm_head": (self.Vl, self.H, False)}
-        # third field: the output may be fp32 slabs of a K split across workgroups (summed by the next kernel)
-        self.tiled_shapes["o"] = (self.H, self.nh * self.d, self.tp_size == 1)
-        self.tiled_shapes["down"] = (self.H, self.F, not self.mlp_sharded)
+        # third field: K may be split across workgroups into fp32 slabs that the next kernel adds up
+        # (attention for qkv; the add + norm kernel, or -- under tensor parallelism, where an
+        # all-reduce sits in between -- mi355_sum_slabs for o and down; the SwiGLU-from-slabs
+        # kernel for gate_up); the lm_head's logits are consumed as they are
+        self.tiled_shapes = {"qkv": (self.qw, self.H, True), "gu": (2 * self.F, self.H, True),
+                             "lm_head": (self.Vl, self.H, False), "o": (self.H, self.nh * self.d, True),
+                             "down": (self.H, self.F, True)}
         ms = []                                       # the kernels' row-count classes a bucket can fall in
-        for m in (16, 32, 64, 128):
+        for m in self.ROW_CLASSES:
             ms.append(m)
             if m >= self.max_num_seqs:
                 break
@@ -237,7 +242,7 @@ class ModelRunner:
                                for k in src if k in self.tiled_shapes})
             if self.single_weight_copy:
                 # The tiled copy becomes the only one: the row-major matrix a library GEMM needs
-                # (prefill, batches beyond 128 rows) is rebuilt from it into a scratch buffer on
+                # (prefill, batches beyond 256 rows) is rebuilt from it into a scratch buffer on
                 # demand (_rm).  Freed layer by layer, so the two copies never coexist for more
                 # than one layer.
                 for k in src:
@@ -249,14 +254,34 @@ class ModelRunner:
                     self._rm_scratch[k] = torch.empty(*self._rm_shape[k], dtype=self.dtype, device=self.device)
         self.lm_head_tiled = ops.tile_weights(self.w.lm_head) if "lm_head" in self.tiled_shapes else None
         f32 = dict(dtype=torch.float32, device=self.device)
-        size = {k: 0 for k in ("qkv", "o", "down")}
-        for m in ms:                                  # room for the deepest K split the tuner may pick (8 slabs)
+        # room for the deepest K split any plan or timed candidate of a row class asks for
+        size = {k: 0 for k in ("qkv", "o", "gu", "down")}
+        for m in ms:
+            rows = min(m, max(self.max_num_seqs, 16))
             for k in size:
-                if k in self._tiled_plan(m) and self.tiled_shapes[k][2]:
-                    size[k] = max(size[k], 8 * min(m, max(self.max_num_seqs, 16)) * self.tiled_shapes[k][0])
+                if k not in self._tiled_plan(m):
+                    continue
+                n, kk, split = self.tiled_shapes[k]
+                deepest = max([g for _, g in self._candidates(k, m)] + [self._tiled_plan(m)[k][1]])
+                size[k] = max(size[k], deepest * rows * n)
         self.part_qkv = torch.empty(max(size["qkv"], 4), **f32)
         self.part_o = torch.empty(max(size["o"], 4), **f32)
         self.part_dn = torch.empty(max(size["down"], 4), **f32)
+        self.part_gu = torch.empty(max(size["gu"], 4), **f32)
+
+    def _candidates(self, kind: str, m: int):
+        """(tiles_per_wg, k_groups) forms of projection `kind` worth timing at m rows."""
+        n, kk, split = self.tiled_shapes[kind]
+        out = []
+        for cand in ops.linear_tiled_candidates(n, kk, split, m, swiglu=(kind == "gu")):
+            if kind == "qkv" and cand[1] > self.QKV_MAX_SLABS:
+                continue
+            # gate_up pays a kernel of its own for taking slabs: worth timing only where the unsplit
+            # launch leaves most of the chip idle (a tensor-parallel rank's slice)
+            if kind == "gu" and cand[1] > 1 and -(-((n + 15) // 16) // 8) >= 160:
+                continue
+            out.append(cand)
+        return out
 
     def _fake_quantize_row_major(self) -> None:
         """--quantization fp8: the row-major matrices (prefill, large batches) are replaced by what
@@ -349,9 +374,54 @@ class ModelRunner:
             best = min(best, s.elapsed_time(e))
         return best * 1e3 / (reps * self.L)
 
+    def _time_after_layers(self, fn, b: int) -> float:
+        """GPU time (us) of fn() when it runs where the lm_head runs in a step: right after the
+        weight streams of all layers.  Timed back to back, a 131-525 MB lm_head is served from the
+        256 MB memory-side cache its own previous launch filled, which flatters whichever form is
+        less bound by HBM (the library GEMM at 128+ rows) -- in the step the layers' weights have
+        passed through that cache in between.  Here every call of fn is preceded by the gate_up
+        weight stream of every layer, and the same launches without fn are timed and subtracted."""
+        x, act, gu = self.x[:b], self.act[:b], self.gu[:b]
+
+        def layers():
+            for i in range(self.L):
+                if self.tiled is not None and "gu" in self.tiled[i]:
+                    t_, g_ = self._tiled_plan(self.bucket_for(b))["gu"]
+                    if g_ > 1:
+                        self._linear_tiled(x, self.tiled[i]["gu"], 2 * self.F, partial=self.part_gu, tiles_per_wg=t_,
+                                           k_groups=g_, epilogue=ops.EPI_PARTIAL)
+                    else:
+                        self._linear_tiled(x, self.tiled[i]["gu"], 2 * self.F, out=act, tiles_per_wg=t_,
+                                           epilogue=ops.EPI_SILU_MUL)
+                else:
+                    torch.mm(x, self._rm(i, "gu").t(), out=gu)
+
+        def run(with_fn: bool) -> float:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                for _ in range(2):
+                    layers()
+                    if with_fn:
+                        fn()
+            g.replay()
+            best = float("inf")
+            for _ in range(3):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                g.replay()
+                e.record()
+                e.synchronize()
+                best = min(best, s.elapsed_time(e))
+            return best * 1e3 / 2
+
+        layers()
+        fn()
+        torch.cuda.synchronize()
+        return max(run(True) - run(False), 0.0)
+
     @staticmethod
     def _row_class(m: int) -> int:
-        return 16 if m <= 16 else 32 if m <= 32 else 64 if m <= 64 else 128
+        return 16 if m <= 16 else 32 if m <= 32 else 64 if m <= 64 else 128 if m <= 128 else 256
 
     def tune(self, bucket: int) -> dict:
         """Decides, for one batch-size bucket, how every projection runs: times the tiled kernel in
@@ -374,58 +444,39 @@ class ModelRunner:
             self.slots.fill_(-1)
             self.in32.zero_()
             slots, ctx, bt, splits = self.slots[:b], self.ctx[:b], self.block_tables[:b], self._splits_for(b)
-            resid, x, qkv, attn, act, o, gu, dn = (t[:b] for t in (self.resid, self.x, self.qkv, self.attn, self.act,
-                                                                  self.o, self.gu, self.dn))
-            W, T, P, eps = self.w.layers, self.tiled, ops.EPI_PARTIAL, self.eps
-            lt = self._linear_tiled
+            resid, x, attn = self.resid[:b], self.x[:b], self.attn[:b]
+            W = self.w.layers
 
             def attend(i, **kw):
                 ops.paged_attn_decode_fused(kw.pop("qkv", None), self.cos_sin, slots, self.k_cache[i], self.v_cache[i],
                                             bt, ctx, self.nh, self.nkv, self.d, self.scale, num_splits=splits,
                                             workspace=self.attn_ws, out=attn, **kw)
 
-            # projection -> (tiled form for a (tiles_per_wg, k_groups) plan, library form)
-            forms = {
-                "qkv": (lambda t_, g_: lambda i: (lt(x, T[i]["qkv"], self.qw, partial=self.part_qkv, tiles_per_wg=t_,
-                                                     k_groups=g_, epilogue=P),
-                                                  attend(i, partial=self.part_qkv, num_slabs=g_, bias=W[i].qkv_b)),
-                        lambda i: (torch.mm(x, self._rm(i, "qkv").t(), out=qkv), attend(i, qkv=qkv))),
-                "o": ((lambda t_, g_: lambda i: (lt(attn, T[i]["o"], self.H, partial=self.part_o, tiles_per_wg=t_,
-                                                    k_groups=g_, epilogue=P),
-                                                 ops.fused_add_rms_norm_partial(self.part_o, g_, resid, W[i].post_norm,
-                                                                                eps, x)))
-                      if self.tp_size == 1 else
-                      (lambda t_, g_: lambda i: (lt(attn, T[i]["o"], self.H, out=o, tiles_per_wg=t_),
-                                                 ops.fused_add_rms_norm(o, resid, W[i].post_norm, eps, out=x))),
-                      lambda i: (torch.mm(attn, self._rm(i, "o").t(), out=o),
-                                 ops.fused_add_rms_norm(o, resid, W[i].post_norm, eps, out=x))),
-                "gu": (lambda t_, g_: lambda i: lt(x, T[i]["gu"], 2 * self.F, out=act, tiles_per_wg=t_,
-                                                   epilogue=ops.EPI_SILU_MUL),
-                       lambda i: (torch.mm(x, self._rm(i, "gu").t(), out=gu), ops.silu_and_mul(gu, out=act))),
-                "down": ((lambda t_, g_: lambda i: (lt(act, T[i]["down"], self.H, partial=self.part_dn, tiles_per_wg=t_,
-                                                       k_groups=g_, epilogue=P),
-                                                    ops.fused_add_rms_norm_partial(self.part_dn, g_, resid,
-                                                                                   W[i].input_norm, eps, x)))
-                         if not self.mlp_sharded else
-                         (lambda t_, g_: lambda i: (lt(act, T[i]["down"], self.H, out=dn, tiles_per_wg=t_),
-                                                    ops.fused_add_rms_norm(dn, resid, W[i].input_norm, eps, out=x))),
-                         lambda i: (torch.mm(act, self._rm(i, "down").t(), out=dn),
-                                    ops.fused_add_rms_norm(dn, resid, W[i].input_norm, eps, out=x))),
-                "lm_head": (lambda t_, g_: lambda i: ops.linear_tiled(x, self.lm_head_tiled, self.Vl,
-                                                                      out=self.logits[:b], tiles_per_wg=t_),
-                            lambda i: torch.mm(x, self.w.lm_head.t(), out=self.logits[:b])),
-            }
+            # projection -> (tiled form for a (tiles_per_wg, k_groups) plan, library form), each with the
+            # kernel(s) that take its output format to the next 16-bit tensor of the step
+            def form(kind):
+                return (lambda t_, g_: lambda i: self._project(kind, i, b, W[i], attend, plan=(t_, g_), tiled=True),
+                        lambda i: self._project(kind, i, b, W[i], attend, tiled=False))
+            forms = {k: form(k) for k in ("qkv", "o", "gu")}
+            forms["down"] = (lambda t_, g_: lambda i: (self._project("down", i, b, W[i], attend, plan=(t_, g_), tiled=True),
+                                                       self._add_mlp_and_norm(b, W[i].input_norm, plan=(t_, g_), tiled=True)),
+                             lambda i: (self._project("down", i, b, W[i], attend, tiled=False),
+                                        self._add_mlp_and_norm(b, W[i].input_norm, tiled=False)))
+            forms["lm_head"] = (lambda t_, g_: lambda i: ops.linear_tiled(x, self.lm_head_tiled, self.Vl,
+                                                                          out=self.logits[:b], tiles_per_wg=t_),
+                                lambda i: torch.mm(x, self.w.lm_head.t(), out=self.logits[:b]))
             self.tune_us = getattr(self, "tune_us", {})
+            self._no_collectives = True                     # the all-reduce costs every form the same: not timed
             try:
                 for k in [k for k in self.KINDS if k in avail]:
                     tiled_form, lib_fn = forms[k]
                     n, kk, split = self.tiled_shapes[k]
                     best, best_us = avail[k], None
-                    for cand in ops.linear_tiled_candidates(n, kk, split, b, swiglu=(k == "gu")):
-                        if k == "qkv" and cand[1] > self.QKV_MAX_SLABS:
-                            continue
+                    # the lm_head is timed where it runs: behind the layers' weight streams (_time_after_layers)
+                    clock = (lambda f: self._time_after_layers(lambda: f(0), b)) if k == "lm_head" else self._time_launches
+                    for cand in self._candidates(k, b):
                         try:
-                            us = self._time_launches(tiled_form(*cand))
+                            us = clock(tiled_form(*cand))
                         except Mi355Error:                  # no kernel of this form for the code (e.g. fp8 with 108)
                             continue
                         # the planner's own choice unless beaten by more than the timing's repeatability
@@ -434,9 +485,9 @@ class ModelRunner:
                         if best_us is None or us < 0.99 * best_us:
                             best, best_us = cand, us
                     if best_us is None:
-                        best_us = self._time_launches(tiled_form(*best))
+                        best_us = clock(tiled_form(*best))
                     lib_fn(0)                               # first library call may pick its algorithm
-                    tl = self._time_launches(lib_fn)
+                    tl = clock(lib_fn)
                     best_us, tl = round(best_us, 2), round(tl, 2)
                     self.tune_us[(bucket, k)] = (best_us, tl)
                     avail[k] = best
@@ -451,6 +502,8 @@ class ModelRunner:
                 torch.cuda.synchronize()
                 avail = dict(self._tiled_plan(bucket))
                 mode = {k: k in avail for k in self.KINDS}
+            finally:
+                self._no_collectives = False
             resid.zero_()                                   # the timed norms accumulated into it
             self.in64.copy_(saved64)
             self.in32.copy_(saved32)
@@ -479,74 +532,108 @@ class ModelRunner:
                 done.add(cls)
                 self.tune(bucket)
 
-    def _decode_layers(self, b: int, slots, bt, ctx, splits) -> None:
-        """All decoder layers + the final norm for b decode tokens held in self.resid[:b]; leaves the
-        normed hidden state in self.x[:b].  Each projection runs as the tiled kernel or as a library
-        GEMM as self._mode(b) says; a K-split tiled projection hands fp32 partial sums to the kernel
-        after it (attention, norm), a library one a 16-bit tensor."""
-        resid, x, qkv, attn, act, o = self.resid[:b], self.x[:b], self.qkv[:b], self.attn[:b], self.act[:b], self.o[:b]
-        gu, dn = self.gu[:b], self.dn[:b]
+    def _project(self, kind: str, i: int, b: int, lw, attend, plan=None, tiled=None) -> None:
+        """Projection `kind` (qkv / o / gu / down) of layer i over b rows, together with the kernels
+        that take its result to the next 16-bit tensor of the step:
+          qkv   x -> [fused rope + KV store + attention] -> attn
+          o     attn -> (all-reduce under tensor parallelism) + residual add + norm -> x
+          gu    x -> SwiGLU -> act
+          down  act -> (all-reduce when the MLP is sharded) -> dn, or slabs for the next add + norm
+        The GEMM is the tiled kernel in the bucket's plan (`plan` / `tiled` override it: the timing
+        runs) or a library GEMM.  A tiled GEMM with K split over workgroups leaves fp32 slabs that
+        the next kernel adds up: attention, the add + norm kernel, mi355_silu_and_mul_slabs, or --
+        where an all-reduce needs a 16-bit tensor first -- mi355_sum_slabs."""
         P = ops.EPI_PARTIAL
-        mode = self._mode(b)
-        plans = self._tiled_plan(self.bucket_for(b)) if any(mode.values()) else {}
-        tq, gq = plans.get("qkv", (0, 1))
-        to, go = plans.get("o", (0, 1))
-        tg, _ = plans.get("gu", (0, 1))
-        td, gd = plans.get("down", (0, 1))
-        tiled = self.tiled if self.tiled is not None else [None] * self.L
-
-        slabs_o, slabs_dn = self.tp_size == 1, not self.mlp_sharded     # else: a 16-bit output for the all-reduce
-
-        def add_mlp_and_norm(weight):
-            if mode["down"] and slabs_dn:
-                ops.fused_add_rms_norm_partial(self.part_dn, gd, resid, weight, self.eps, x)
+        if tiled is None:
+            tiled = self._mode(b)[kind]
+        if tiled and plan is None:
+            plan = self._tiled_plan(self.bucket_for(b))[kind]
+        t_, g_ = plan if tiled else (0, 1)
+        tw = self.tiled[i] if self.tiled is not None else None
+        resid, x, attn, act = self.resid[:b], self.x[:b], self.attn[:b], self.act[:b]
+        if kind == "qkv":
+            if tiled:
+                self._linear_tiled(x, tw["qkv"], self.qw, partial=self.part_qkv, tiles_per_wg=t_, k_groups=g_, epilogue=P)
+                attend(i, partial=self.part_qkv, num_slabs=g_, bias=lw.qkv_b)
             else:
-                ops.fused_add_rms_norm(dn, resid, weight, self.eps, out=x)
-
-        for i, (lw, tw) in enumerate(zip(self.w.layers, tiled)):
-            if i > 0:           # layer 0's input norm ran with the embedding gather
-                add_mlp_and_norm(lw.input_norm)
-            if mode["qkv"]:
-                self._linear_tiled(x, tw["qkv"], self.qw, partial=self.part_qkv, tiles_per_wg=tq, k_groups=gq,
-                                   epilogue=P)
-                ops.paged_attn_decode_fused(None, self.cos_sin, slots, self.k_cache[i], self.v_cache[i], bt, ctx,
-                                            self.nh, self.nkv, self.d, self.scale, num_splits=splits,
-                                            workspace=self.attn_ws, out=attn, partial=self.part_qkv, num_slabs=gq,
-                                            bias=lw.qkv_b)
-            else:
+                qkv = self.qkv[:b]
                 if lw.qkv_b is None:
                     torch.mm(x, self._rm(i, "qkv").t(), out=qkv)
                 else:
                     torch.addmm(lw.qkv_b, x, self._rm(i, "qkv").t(), out=qkv)
-                ops.paged_attn_decode_fused(qkv, self.cos_sin, slots, self.k_cache[i], self.v_cache[i], bt, ctx,
-                                            self.nh, self.nkv, self.d, self.scale, num_splits=splits,
-                                            workspace=self.attn_ws, out=attn)
-            if mode["o"] and slabs_o:
-                self._linear_tiled(attn, tw["o"], self.H, partial=self.part_o, tiles_per_wg=to, k_groups=go, epilogue=P)
-                ops.fused_add_rms_norm_partial(self.part_o, go, resid, lw.post_norm, self.eps, x)
+                attend(i, qkv=qkv)
+        elif kind == "o":
+            o = self.o[:b]
+            if tiled and self.tp_size == 1:               # the add + norm kernel sums the slabs (one slab too)
+                self._linear_tiled(attn, tw["o"], self.H, partial=self.part_o, tiles_per_wg=t_, k_groups=g_, epilogue=P)
+                ops.fused_add_rms_norm_partial(self.part_o, g_, resid, lw.post_norm, self.eps, x)
+                return
+            if tiled and g_ > 1:
+                self._linear_tiled(attn, tw["o"], self.H, partial=self.part_o, tiles_per_wg=t_, k_groups=g_, epilogue=P)
+                self._allreduce_slabs(self.part_o, g_, o)
             else:
-                if mode["o"]:
-                    self._linear_tiled(attn, tw["o"], self.H, out=o, tiles_per_wg=to)
+                if tiled:
+                    self._linear_tiled(attn, tw["o"], self.H, out=o, tiles_per_wg=t_)
                 else:
                     torch.mm(attn, self._rm(i, "o").t(), out=o)
                 self._allreduce(o)
-                ops.fused_add_rms_norm(o, resid, lw.post_norm, self.eps, out=x)
-            if mode["gu"]:
-                self._linear_tiled(x, tw["gu"], 2 * self.F, out=act, tiles_per_wg=tg, epilogue=ops.EPI_SILU_MUL)
+            ops.fused_add_rms_norm(o, resid, lw.post_norm, self.eps, out=x)
+        elif kind == "gu":
+            if tiled and g_ > 1:
+                self._linear_tiled(x, tw["gu"], 2 * self.F, partial=self.part_gu, tiles_per_wg=t_, k_groups=g_, epilogue=P)
+                ops.silu_and_mul_slabs(self.part_gu, g_, act)
+            elif tiled:
+                self._linear_tiled(x, tw["gu"], 2 * self.F, out=act, tiles_per_wg=t_, epilogue=ops.EPI_SILU_MUL)
             else:
+                gu = self.gu[:b]
                 torch.mm(x, self._rm(i, "gu").t(), out=gu)
                 ops.silu_and_mul(gu, out=act)
-            if mode["down"] and slabs_dn:
-                self._linear_tiled(act, tw["down"], self.H, partial=self.part_dn, tiles_per_wg=td, k_groups=gd,
-                                   epilogue=P)
+        elif kind == "down":
+            dn = self.dn[:b]
+            if tiled and not self.mlp_sharded:            # slabs for the add + norm kernel that follows (_add_mlp_and_norm)
+                self._linear_tiled(act, tw["down"], self.H, partial=self.part_dn, tiles_per_wg=t_, k_groups=g_, epilogue=P)
+                return
+            if tiled and g_ > 1:
+                self._linear_tiled(act, tw["down"], self.H, partial=self.part_dn, tiles_per_wg=t_, k_groups=g_, epilogue=P)
+                self._allreduce_slabs(self.part_dn, g_, dn)
             else:
-                if mode["down"]:
-                    self._linear_tiled(act, tw["down"], self.H, out=dn, tiles_per_wg=td)
+                if tiled:
+                    self._linear_tiled(act, tw["down"], self.H, out=dn, tiles_per_wg=t_)
                 else:
                     torch.mm(act, self._rm(i, "down").t(), out=dn)
                 if self.mlp_sharded:
                     self._allreduce(dn)
-        add_mlp_and_norm(self.w.final_norm)
+        else:
+            raise ValueError(kind)
+
+    def _add_mlp_and_norm(self, b: int, weight, plan=None, tiled=None) -> None:
+        """Residual add of the MLP output + the norm that follows it: from the down projection's slabs
+        when it left slabs (tiled, MLP not sharded), from its 16-bit result otherwise."""
+        if tiled is None:
+            tiled = self._mode(b)["down"]
+        if tiled and not self.mlp_sharded:
+            g_ = (plan or self._tiled_plan(self.bucket_for(b))["down"])[1]
+            ops.fused_add_rms_norm_partial(self.part_dn, g_, self.resid[:b], weight, self.eps, self.x[:b])
+        else:
+            ops.fused_add_rms_norm(self.dn[:b], self.resid[:b], weight, self.eps, out=self.x[:b])
+
+    def _decode_layers(self, b: int, slots, bt, ctx, splits) -> None:
+        """All decoder layers + the final norm for b decode tokens held in self.resid[:b]; leaves the
+        normed hidden state in self.x[:b].  Each projection runs as the tiled kernel or as a library
+        GEMM as self._mode(b) says (_project)."""
+        attn = self.attn[:b]
+
+        def attend(i, qkv=None, **kw):
+            ops.paged_attn_decode_fused(qkv, self.cos_sin, slots, self.k_cache[i], self.v_cache[i], bt, ctx,
+                                        self.nh, self.nkv, self.d, self.scale, num_splits=splits,
+                                        workspace=self.attn_ws, out=attn, **kw)
+
+        for i, lw in enumerate(self.w.layers):
+            if i > 0:           # layer 0's input norm ran with the embedding gather
+                self._add_mlp_and_norm(b, lw.input_norm)
+            for kind in ("qkv", "o", "gu", "down"):
+                self._project(kind, i, b, lw, attend)
+        self._add_mlp_and_norm(b, self.w.final_norm)
 
     def lm_head_logits(self, x: torch.Tensor, out: torch.Tensor) -> None:
         """Decode-step logits of the rows in x."""
@@ -636,12 +723,23 @@ class ModelRunner:
         """Sum of the ranks' partial results, in place.  Decode-sized 16-bit messages take the one-shot
         kernel over peer-mapped buffers when the engine was built with one (every rank adds in rank
         order: bit-identical results); everything else the process group's all-reduce."""
-        if self.tp_size > 1:
+        if self.tp_size > 1 and not self._no_collectives:
             if self.oneshot is not None and self.oneshot.fits(t):
                 self.oneshot.run(t)
                 self.oneshot_calls += 1
             else:
                 self._collective(lambda c: torch.distributed.all_reduce(c, group=self.tp_group), t)
+
+    def _allreduce_slabs(self, partial: torch.Tensor, num_slabs: int, out: torch.Tensor) -> None:
+        """All-reduce of a K-split projection's result: the slabs are added up and rounded into `out`
+        (the 16-bit partial result of this rank), which is then summed over the ranks in place."""
+        if self.oneshot is not None and self.oneshot.fits(out) and not self._no_collectives:
+            # the slab sum is formed inside the all-reduce launch (no launch of its own)
+            self.oneshot.run_slabs(partial, num_slabs, out)
+            self.oneshot_calls += 1
+            return
+        ops.sum_slabs(partial, num_slabs, out)
+        self._allreduce(out)
 
     def _layers(self, n: int, resid, x, qkv, attn, o, gu, act, dn, attend) -> torch.Tensor:
         """Runs all decoder layers over n packed tokens held in `resid`.  Returns the
@@ -811,6 +909,8 @@ class ModelRunner:
             self._sample(logits, sampling, nxt, stage)
         self._ids_synced = sampling is None          # re-drawn rows are in next_ids only
         self.h_nexts[stage][:batch].copy_(nxt, non_blocking=True)
+        if self.oneshot is not None:
+            self.oneshot.queue_status(stage)              # the communicator's error word travels with the step's tokens
         if logprobs >= 0:
             self.h_lp[stage][:batch, : 1 + 2 * logprobs].copy_(self._logprobs(logits, nxt, logprobs),
                                                                non_blocking=True)
@@ -821,9 +921,9 @@ class ModelRunner:
         `logprobs` >= 0 as at launch, the per-row log-probabilities from _unpack_logprobs)."""
         self.done[stage].synchronize()
         if self.oneshot is not None:
-            self._finished = getattr(self, "_finished", 0) + 1
-            if self._finished % 64 == 0:
-                self.oneshot.check()                  # a peer that never arrived: raise instead of serving garbage
+            # a peer that never arrived left this rank's activations un-reduced: raise in the very step
+            # that hit it (the engine thread then fails, /health turns 500 and the process exits non-zero)
+            self.oneshot.raise_if_failed(stage)
         toks = self.h_nexts[stage][:batch].tolist()
         if logprobs < 0:
             return toks
@@ -856,6 +956,8 @@ class ModelRunner:
                                    want_logits=sampling is not None or logprobs >= 0, score=score)
         if sampling is not None:
             self._sample(logits, sampling, nxt)
+        if self.oneshot is not None:
+            self.oneshot.check()                          # synchronises (a prefill waits for its tokens anyway)
         if logprobs >= 0:
             lp = self._logprobs(logits, nxt, logprobs).cpu().numpy()
             res = nxt.cpu().tolist(), self._unpack_logprobs(lp, logprobs)

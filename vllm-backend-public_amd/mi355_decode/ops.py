@@ -300,6 +300,31 @@ def silu_and_mul(x: torch.Tensor, out: torch.Tensor | None = None):
     return out
 
 
+def sum_slabs(partial: torch.Tensor, num_slabs: int, out: torch.Tensor, bias: torch.Tensor | None = None):
+    """out[M, N] = round(sum of the first num_slabs fp32 slabs of `partial` ([num_slabs, M, N], flat is fine) + bias),
+    slabs added in slab order: the 16-bit tensor an all-reduce needs from a K-split projection."""
+    dt = _dt16(out, "out")
+    M, N = out.shape
+    _check_partial(partial, num_slabs, M, N)
+    if bias is not None and (bias.dtype != out.dtype or bias.numel() != N or not bias.is_contiguous()):
+        raise ValueError("bias must be contiguous [N] in the dtype of out")
+    check(lib.mi355_sum_slabs(out.data_ptr(), _rows(out, "out"), partial.data_ptr(), num_slabs,
+                              bias.data_ptr() if bias is not None else 0, M, N, dt, _stream()))
+    return out
+
+
+def silu_and_mul_slabs(partial: torch.Tensor, num_slabs: int, out: torch.Tensor):
+    """SwiGLU from the slabs of a K-split gate_up projection on weights tiled with interleave_halves
+    ([num_slabs, M, 2F], 16-column tiles alternating gate / up): out[M, F], the values the GEMM's own
+    SwiGLU epilogue would have produced from the same sums."""
+    dt = _dt16(out, "out")
+    M, F = out.shape
+    _check_partial(partial, num_slabs, M, 2 * F)
+    check(lib.mi355_silu_and_mul_slabs(out.data_ptr(), _rows(out, "out"), partial.data_ptr(), num_slabs, M, 2 * F, dt,
+                                       _stream()))
+    return out
+
+
 def argmax(logits: torch.Tensor, out: torch.Tensor | None = None):
     _dev(logits, "logits")
     if logits.dtype not in _DT:
@@ -507,7 +532,7 @@ def sample(logits: torch.Tensor, temperature: torch.Tensor, top_k: torch.Tensor,
 
 EPI_STORE, EPI_SILU_MUL, EPI_PARTIAL, EPI_REDUCE_STORE, EPI_REDUCE_RESID = 0, 1, 2, 3, 4
 SUMSQ_ROWS = 32                      # row pitch of the sum-of-squares tables
-LINEAR_TILED_MAX_M = 128
+LINEAR_TILED_MAX_M = 256             # beyond 128 rows: two row blocks of one launch
 
 
 KW_CODES = (302, 304, 308, 402, 404)   # K split across 2 / 4 / 8 waves of an 8-wave workgroup (4xx: 512-wide x slices)
@@ -549,7 +574,7 @@ def plan_linear_tiled(N: int, K: int, split_k: bool, M: int = 32):
         if K % ksl:
             continue
         units = K // ksl
-        wgs = -(-tiles_total // (tiles % 100))
+        wgs = -(-tiles_total // (tiles % 100)) * (-(-M // 128))          # beyond 128 rows: two row blocks
         groups = 1
         if split_k and wgs < 160:
             # at most 8 slabs: the consumers (attention, norm) sum up to 8 with straight-line loads
@@ -578,12 +603,13 @@ def linear_tiled_candidates(N: int, K: int, split_k: bool, M: int = 32, swiglu: 
         return []
     out = [first]
     tiles_total = (N + 15) // 16
+    row_blocks = -(-M // 128)
     for tiles in ((8, 104, 108) if M <= 32 else (8, 104, 108, 208, 216, 210, 212, 214) if M <= 64
                   else (8, 216, 210, 212, 214)):
         ksl = tiled_slice_width(M, tiles)
         if K % ksl:
             continue
-        wgs = -(-tiles_total // tiles_per_workgroup(tiles))
+        wgs = -(-tiles_total // tiles_per_workgroup(tiles)) * row_blocks
         for g in ((1, 2, 4, 8) if split_k else (1,)):
             if g <= K // ksl and 64 <= wgs * g <= 1024 and (tiles, g) not in out:
                 out.append((tiles, g))
@@ -594,7 +620,7 @@ def linear_tiled_candidates(N: int, K: int, split_k: bool, M: int = 32, swiglu: 
             ksl = tiled_slice_width(M, tiles)
             if K % ksl or (swiglu and tiles % 100 > 4) or (tiles % 100) * 128 > ksl:   # a wave needs a register group of the slice
                 continue
-            wgs = -(-tiles_total // tiles_per_workgroup(tiles))
+            wgs = -(-tiles_total // tiles_per_workgroup(tiles)) * row_blocks
             for g in ((1, 2, 4, 8) if split_k else (1,)):
                 if g <= K // ksl and 48 <= wgs * g <= 1024 and (tiles, g) not in out:
                     out.append((tiles, g))
@@ -642,7 +668,7 @@ def untile_weights(w_tiled, N: int, K: int, dtype: torch.dtype, interleave_halve
 def linear_tiled(x: torch.Tensor, w_tiled: torch.Tensor, N: int, bias: torch.Tensor | None = None,
                  out: torch.Tensor | None = None, partial: torch.Tensor | None = None, tiles_per_wg: int = 0,
                  k_groups: int = 1, epilogue: int = EPI_STORE):
-    """y = x @ W.T on fragment-tiled weights (M <= 128).  Returns `out`
+    """y = x @ W.T on fragment-tiled weights (M <= 256).  Returns `out`
     ([M, N], or [M, N/2] with the SwiGLU epilogue) or `partial` ([k_groups, M, N] fp32)."""
     dt = _dt16(x, "x")
     _dev(w_tiled, "w_tiled")
