@@ -8,8 +8,8 @@
 //   1. copies chunk b of its input into slot[parity][r] of EVERY rank's buffer (all links of a
 //      fully connected node carry data at once -- a ring pushes the message through one link
 //      per hop),
-//   2. makes the stores visible (system-scope fence) and writes the round number to
-//      flag[r][b] of every rank,
+//   2. waits until its stores have been acknowledged (the buffers are uncached, the stores
+//      system-scope: no fence, see below) and writes the round number to flag[r][b] of every rank,
 //   3. waits until flag[p][b] of its own buffer has reached the round for every p,
 //   4. sums chunk b of the world slots in RANK ORDER in fp32 and writes the rounded result
 //      over its input -- every rank adds the same values in the same order, so the results
@@ -32,7 +32,7 @@
 namespace mi355 {
 
 constexpr int kArMaxWorld = 8;
-constexpr int kArMaxBlocks = 64;
+constexpr int kArMaxBlocks = 256;
 constexpr int kArThreads = 256;
 constexpr long long kSpinLimitTicks = 200000000LL;   // 2 s of the 100 MHz wall clock
 
@@ -57,6 +57,30 @@ __host__ __device__ inline int64_t ar_flags_offset(int world, int64_t max_bytes)
 inline int64_t ar_buffer_bytes(int world, int64_t max_bytes) {
   return ar_flags_offset(world, max_bytes) + static_cast<int64_t>(world) * kArMaxBlocks * sizeof(unsigned);
 }
+
+// Accesses to the exchange buffers.  The buffers are fine-grained (uncached) device memory and the
+// peers map them as such: no cache level holds their lines, so a store is where its readers look
+// once it has been acknowledged (the wave's vmcnt has drained), and a load finds what was last
+// stored.  Every access carries system scope (sc0 sc1) on top, so that this does not rest on the
+// mapping alone.  What the kernel does NOT do is fence: a system-scope release or acquire fence
+// writes back / invalidates the whole L2 -- with the dirty fp32 slabs of the GEMM that ran just
+// before it, several microseconds per call, 64-160 calls per step -- for data that is not in it.
+typedef unsigned int ar_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void ar_store_sys(void* p, uint4 v) {
+  const ar_u32x4 r = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(r) : "memory");
+}
+__device__ __forceinline__ ar_u32x4 ar_load_sys(const void* p) {   // the result may be used only behind ar_wait_loads
+  ar_u32x4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ void ar_wait_loads(ar_u32x4& r) {       // ties the value to the wait: no use can move above it
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(r)::"memory");
+}
+
+constexpr int kArVecPerThread = 2;   // 16-byte vectors a thread holds in flight per pass
 
 // `slabs` != nullptr: this rank's input is not `data` but round(slabs[0] + slabs[1] + ...), fp32
 // partial sums [num_slabs][count] of a projection whose K was split over workgroups, added in slab
@@ -86,22 +110,23 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       for (int g = 0; g < num_slabs; ++g) {
         const float4* sp = reinterpret_cast<const float4*>(slabs + g * count + 8 * v);
-        const float4 a = sp[0], b = sp[1];
+        const float4 a = sp[0], b4 = sp[1];
         acc[0] += a.x, acc[1] += a.y, acc[2] += a.z, acc[3] += a.w;
-        acc[4] += b.x, acc[5] += b.y, acc[6] += b.z, acc[7] += b.w;
+        acc[4] += b4.x, acc[5] += b4.y, acc[6] += b4.z, acc[7] += b4.w;
       }
       mine_v = pack8<T>(acc);
     } else {
       mine_v = src[v];
     }
-    for (int p = 0; p < world; ++p) reinterpret_cast<uint4*>(peers.buf[p] + slot_off)[v] = mine_v;
+    for (int p = 0; p < world; ++p) ar_store_sys(peers.buf[p] + slot_off + v * 16, mine_v);
   }
-  // 2. stores first, then the flag: release at system scope, by every thread that stored
-  __threadfence_system();
+  // 2. stores first, then the flag: every storing wave waits until its stores have been acknowledged,
+  //    the workgroup meets, then one lane per peer raises this chunk's flag there
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid < world) {
     unsigned* flag = reinterpret_cast<unsigned*>(peers.buf[tid] + flags_off) + rank * kArMaxBlocks + b;
-    __hip_atomic_store(flag, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(flag, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   // 3. wait for chunk b of every rank (bounded)
   __shared__ int ok_s;
@@ -112,38 +137,52 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
     const long long t0 = wall_clock64();
     bool ok = true;
     // rounds are compared modulo 2^32: "reached" = not more than half the range behind
-    while (static_cast<int>(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - round) < 0) {
+    while (static_cast<int>(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - round) < 0) {
       if (wall_clock64() - t0 > kSpinLimitTicks) {
         ok = false;
         break;
       }
-      __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_s_sleep(2);
     }
     if (!ok) {
       ok_s = 0;
       atomicExch(error, 1u + static_cast<unsigned>(tid));     // which peer did not arrive
     }
   }
-  __syncthreads();
+  __syncthreads();                                    // the data loads below come after every flag was seen
   const bool ok_all = ok_s != 0;
   if (ok_all) {
-    __threadfence_system();                           // acquire for the data loads of every thread
-
-  // 4. sum in rank order, fp32, one rounding
-  const unsigned char* mine = peers.buf[rank] + static_cast<int64_t>(parity) * world * slot_bytes;
-  uint4* out = reinterpret_cast<uint4*>(data);
-  for (int64_t v = v0 + tid; v < v1; v += kArThreads) {
-    float acc[8];
+    // 4. sum in rank order, fp32, one rounding; the loads of a pass (vectors x ranks) are all in flight together
+    const unsigned char* mine = peers.buf[rank] + static_cast<int64_t>(parity) * world * slot_bytes;
+    uint4* out = reinterpret_cast<uint4*>(data);
+    for (int64_t vb = v0 + tid; vb < v1; vb += kArVecPerThread * kArThreads) {
+      ar_u32x4 in[kArVecPerThread][kArMaxWorld];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int p = 0; p < world; ++p) {
-      float f[8];
-      unpack8<T>(reinterpret_cast<const uint4*>(mine + p * slot_bytes)[v], f);
+      for (int j = 0; j < kArVecPerThread; ++j) {
+        const int64_t v = min(vb + j * kArThreads, v1 - 1);        // clamped: a surplus load re-reads the last vector
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+        for (int p = 0; p < kArMaxWorld; ++p)
+          if (p < world) in[j][p] = ar_load_sys(mine + p * slot_bytes + v * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < kArVecPerThread; ++j) {
+        const int64_t v = vb + j * kArThreads;
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int p = 0; p < kArMaxWorld; ++p) {
+          if (p < world) {
+            ar_wait_loads(in[j][p]);
+            float f[8];
+            unpack8<T>(make_uint4(in[j][p].x, in[j][p].y, in[j][p].z, in[j][p].w), f);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] += f[q];
+          }
+        }
+        if (v < v1) out[v] = pack8<T>(acc);
+      }
     }
-    out[v] = pack8<T>(acc);
-  }
   }   // a timed-out wait leaves the input as it was; the host sees the error word
   // the last workgroup to finish spends the round (a failed call too: the peers' flags stay comparable)
   __syncthreads();
@@ -227,8 +266,9 @@ static int32_t allreduce_oneshot_launch(const char* name, void* comm, void* data
   if (count == 0) return MI355_OK;
   ArPeers peers;
   for (int p = 0; p < kArMaxWorld; ++p) peers.buf[p] = c->peer[p < c->world ? p : c->rank];
-  // one workgroup per 16 KB, the SAME count on every rank (it only depends on `count`)
-  int nb = static_cast<int>((count * 2 + 16383) / 16384);
+  // one workgroup per 8 KB (two 16-byte vectors a thread: one pass of loads), the SAME count on every
+  // rank (it only depends on `count`)
+  int nb = static_cast<int>((count * 2 + 8191) / 8192);
   nb = nb < 1 ? 1 : nb > kArMaxBlocks ? kArMaxBlocks : nb;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == MI355_BF16)
