@@ -366,23 +366,25 @@ int32_t mi355_argmax_key_to_index(int64_t* out_ids, const int64_t* keys,
                                   int32_t num_rows, void* stream);
 
 /*
- * Random sampling with temperature, top-k and top-p, one row per sequence.
- * Candidates = the k highest logits (k = top_k[b] if 0 < top_k[b] <= 1024, else
- * 1024; ties at the threshold by lowest index) ordered by (logit desc, index
- * asc); w_i = exp((logit_i - logit_0) / temperature[b]); top_p[b] < 1 keeps the
- * shortest prefix whose cumulative weight reaches top_p * total; one uniform
- * number from a counter hash of (seeds[b], steps[b]) picks the token by inverse
- * CDF.  All of it is fixed-order fp32 arithmetic: a (logits, parameters, seed,
- * step) tuple always yields the same token, on any launch.  Rows with
- * temperature[b] <= 0 get the greedy token (mi355_argmax semantics); a row that
- * holds a NaN yields the index of its first NaN from either.  A row with neither
- * cut (top_k[b] <= 0 and top_p[b] >= 1) draws from the WHOLE vocabulary, in the
- * Gumbel-max form: token = argmax_i(logit_i / temperature[b] - ln(-ln(u_i))) with
- * one uniform u_i per (seeds[b], steps[b], i) from the same counter hash, ties to
- * the lowest index, the same fixed-order fp32 arithmetic.  With a cut the candidate
- * set never exceeds the 1024 most likely tokens: top_p < 1 with top_k <= 0 keeps a
- * nucleus inside those 1024 (the server rejects top_k > 1024).  Serves
- * temperature/top_k/top_p/seed of POST /v1/completions
+ * Random sampling with temperature, top-k and top-p, one row per sequence, with the kept set
+ * the published samplers define (top-k, then top-p over what top-k kept, both on
+ * logits / temperature -- HF's TopKLogitsWarper + TopPLogitsWarper, the stock engine's mask):
+ *   top_k[b] in (0, vocab)  keeps every token whose logit reaches the k-th largest logit
+ *                           (ties at that value all stay); any k up to the vocabulary
+ *   top_p[b] < 1            orders the survivors by (logit desc, index asc) and keeps the
+ *                           shortest prefix whose probability mass reaches top_p of the
+ *                           survivors' mass -- of the WHOLE vocabulary when top-k is off --
+ *                           the crossing token included, never fewer than one
+ * Masses are exact integers, F_i = floor(exp((logit_i - logit_max) / temperature[b]) * 2^40)
+ * summed in 64 bits, the threshold max(1, ceil(double(top_p) * double(total))): no rounding, so
+ * the set does not depend on any order of additions.  The token is drawn from the kept set
+ * (the whole row when neither cut is set) in the Gumbel-max form,
+ * token = argmax_i(logit_i / temperature[b] - ln(-ln(u_i))), one uniform u_i per
+ * (seeds[b], steps[b], i) from a counter hash, ties to the lowest index; exp and ln are fixed
+ * polynomial forms in fp32.  A (logits, parameters, seed, step) tuple therefore always yields
+ * the same token, on any launch.  Rows with temperature[b] <= 0 get the greedy token
+ * (mi355_argmax semantics); a row that holds a NaN yields the index of its first NaN from
+ * either.  Serves temperature/top_k/top_p/seed of POST /v1/completions
  * (benchmark-deployer/docs/deployment/post_run.md:46).
  */
 int32_t mi355_sample_topk_topp(int64_t* out_ids, const void* logits,

@@ -15,6 +15,8 @@ Three groups of fixtures:
                         embedding + OPTLearnedPositionalEmbedding sum
   tiny_<model>.npz      greedy generations + logits of seeded tiny checkpoints
                         (oracle/tiny_models.py) run by HF in fp32 and bf16
+  sampling_kept_hf.npz  which tokens HF's TopKLogitsWarper / TopPLogitsWarper keep for the rows of
+                        oracle/sampling_cases.py (bit masks)
   harness_launch.json   container args / env / resources / labels produced by
                         the reference's own benchmark-vllm/models.py and
                         vllm_templates.py for the BASELINE configs and its YAML
@@ -394,6 +396,35 @@ def gen_plugin():
     print("harness_plugin.json:", list(cases))
 
 
+def gen_sampling_kept():
+    """Which tokens HF transformers' sampling warpers keep (TemperatureLogitsWarper, then
+    TopKLogitsWarper, then TopPLogitsWarper -- the published top-k / nucleus definition, the order
+    `generate` applies them in) for the rows of oracle/sampling_cases.py -> sampling_kept_hf.npz: one
+    packed bit mask per case.  The numpy oracle's kept set (ops_ref.sample_kept_mask) is compared
+    with them here, at generation time, and in tests/test_oracle_golden.py."""
+    import torch
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+
+    from oracle import ops_ref as R
+    from oracle.sampling_cases import CASES, kept_sets_agree, row_of
+    out = {}
+    for name, (V, kind, t, k, p) in CASES.items():
+        row = row_of(name)
+        scores = torch.from_numpy(row)[None].clone()
+        scores = TemperatureLogitsWarper(float(t))(None, scores)
+        if k > 0:
+            scores = TopKLogitsWarper(int(k))(None, scores)
+        if p < 1:
+            scores = TopPLogitsWarper(float(p))(None, scores)
+        kept = torch.isfinite(scores[0]).numpy()
+        ours = R.sample_kept_mask(row, t, k, p)
+        same = kept_sets_agree(row, kept, ours)
+        print(f"sampling kept set {name}: HF keeps {int(kept.sum())} of {V}; oracle {'agrees' if same else 'DIFFERS'}")
+        assert same, name
+        out[name] = np.packbits(kept)
+    np.savez_compressed(os.path.join(GOLD, "sampling_kept_hf.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["ops", "tiny", "harness"]
@@ -410,3 +441,5 @@ if __name__ == "__main__":
         gen_harness()
     if "plugin" in which or not sys.argv[1:]:
         gen_plugin()
+    if "sampling" in which or not sys.argv[1:]:
+        gen_sampling_kept()

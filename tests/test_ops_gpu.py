@@ -10,6 +10,8 @@ Bars (written next to each check):
     dtype before the PV product: |err| <= 8e-3 * max|ref| for bf16,
     <= 1e-3 * max|ref| for fp16 (the north-star tolerance), plus one output ulp.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -17,6 +19,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
+from conftest import GOLDEN  # noqa: E402
 from oracle import ops_ref as R  # noqa: E402
 
 DT = {"bfloat16": torch.bfloat16, "float16": torch.float16}
@@ -678,7 +681,7 @@ def test_sample_cut_corner_rows(ops):
 
 
 def test_sample_distribution(ops):
-    """Frequencies over many (seed, step) pairs follow softmax(logits / T) over the top-k."""
+    """Frequencies over many (seed, step) pairs follow softmax(logits / T) over the top-k set."""
     rng = rng_for("sample-dist")
     V, k, T, n = 4096, 8, 0.8, 4096
     row = R.round_to((rng.standard_normal(V) * 2).astype(np.float32), "bfloat16")
@@ -686,7 +689,8 @@ def test_sample_distribution(ops):
     out = ops.sample(lg, torch.full((n,), T, device="cuda"), torch.full((n,), k, dtype=torch.int32, device="cuda"),
                      torch.ones(n, device="cuda"), torch.arange(n, device="cuda") * 7919 + 3,
                      torch.arange(n, device="cuda")).cpu().numpy()
-    top = np.argsort(-row.astype(np.float64), kind="stable")[:k]
+    top = np.flatnonzero(R.sample_kept_mask(row, T, k, 1.0))      # the k largest and every token tied with the k-th
+    assert k <= len(top) <= k + 4
     p = np.exp((row[top] - row[top].max()) / T)
     p /= p.sum()
     assert set(out) <= set(top)
@@ -745,6 +749,68 @@ def test_sample_full_vocabulary_distribution(ops):
     assert abs(tail[out].mean() - p[tail].sum()) < 4 * np.sqrt(p[tail].sum() / n)
     for t in range(8):
         assert abs((out == t).mean() - p[t]) < 4 * np.sqrt(p[t] / n) + 1e-3
+
+
+def test_sample_kept_set_is_the_hf_warpers_set(ops):
+    """The rows of oracle/sampling_cases.py: every draw equals the oracle's (whose kept set is pinned to HF
+    transformers' TopKLogitsWarper / TopPLogitsWarper in tests/test_oracle_golden.py), and no draw leaves the
+    set HF keeps (tests/golden/sampling_kept_hf.npz) except among the equal logits at the cut, where HF's order
+    is unspecified.  Covers the list path, the exact path (top_k beyond 1024, a nucleus of thousands) and the
+    Llama-3 vocabulary."""
+    from oracle.sampling_cases import CASES, row_of
+    z = np.load(os.path.join(GOLDEN, "sampling_kept_hf.npz"))
+    n = 48
+    for name, (V, kind, t, k, p) in CASES.items():
+        row = row_of(name)
+        hf = np.unpackbits(z[name])[:V].astype(bool)
+        lg = torch.from_numpy(np.tile(row, (n, 1))).to(torch.bfloat16).cuda()
+        temperature, top_k, top_p = np.full(n, t, np.float32), np.full(n, k, np.int32), np.full(n, p, np.float32)
+        seeds, steps = (np.arange(n, dtype=np.int64) * 104729 + 11), np.arange(n, dtype=np.int64) % 7
+        out = ops.sample(lg, torch.from_numpy(temperature).cuda(), torch.from_numpy(top_k).cuda(),
+                         torch.from_numpy(top_p).cuda(), torch.from_numpy(seeds).cuda(),
+                         torch.from_numpy(steps).cuda()).cpu().numpy()
+        np.testing.assert_array_equal(out, R.sample_topk_topp(np.tile(row, (n, 1)), temperature, top_k, top_p, seeds, steps),
+                                      err_msg=name)
+        cut = row[hf].min()
+        assert (hf[out] | (row[out] == cut)).all(), name
+        assert (row[out] >= cut).all(), name
+
+
+def test_sample_whole_vocabulary_nucleus_distribution(ops):
+    """top_p over the WHOLE vocabulary: on a flat row the 0.9 nucleus holds thousands of tokens; the draws never
+    leave it, tokens beyond the 1024 most likely ones are drawn with their renormalised mass, and so are the
+    most likely ones."""
+    rng = rng_for("sample-nucleus-dist")
+    V, T, p, n = 8192, 1.3, 0.9, 8192
+    row = (rng.standard_normal(V) * 0.5).astype(np.float32)
+    row[:8] += 3.0
+    row = R.round_to(row, "bfloat16")
+    kept = R.sample_kept_mask(row, T, -1, p)
+    assert kept.sum() > 3000
+    lg = torch.from_numpy(np.tile(row, (n, 1))).to(torch.bfloat16).cuda()
+    out = ops.sample(lg, torch.full((n,), T, device="cuda"), torch.full((n,), -1, dtype=torch.int32, device="cuda"),
+                     torch.full((n,), p, device="cuda"), torch.arange(n, device="cuda") * 7919 + 3,
+                     torch.arange(n, device="cuda") % 101).cpu().numpy()
+    assert kept[out].all()
+    q = np.where(kept, np.exp(row.astype(np.float64) / T), 0.0)
+    q /= q.sum()
+    tail = np.zeros(V, bool)
+    tail[np.argsort(-row, kind="stable")[1024:]] = True
+    tail &= kept
+    assert q[tail].sum() > 0.3
+    assert abs(tail[out].mean() - q[tail].sum()) < 4 * np.sqrt(q[tail].sum() / n)
+    for t in range(8):
+        assert abs((out == t).mean() - q[t]) < 4 * np.sqrt(q[t] / n) + 1e-3
+    # the same row with top_k = 3000 (beyond the list: the exact path) and no top-p
+    kept_k = R.sample_kept_mask(row, T, 3000, 1.0)
+    out = ops.sample(lg, torch.full((n,), T, device="cuda"), torch.full((n,), 3000, dtype=torch.int32, device="cuda"),
+                     torch.ones(n, device="cuda"), torch.arange(n, device="cuda") * 7919 + 3,
+                     torch.arange(n, device="cuda") % 101).cpu().numpy()
+    assert kept_k.sum() >= 3000 and kept_k[out].all()
+    qk = np.where(kept_k, np.exp(row.astype(np.float64) / T), 0.0)
+    qk /= qk.sum()
+    for t in range(8):
+        assert abs((out == t).mean() - qk[t]) < 4 * np.sqrt(qk[t] / n) + 1e-3
 
 
 # --------------------------------------------------------------------------- #

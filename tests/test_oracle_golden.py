@@ -5,7 +5,9 @@ the oracle."""
 import numpy as np
 import pytest
 
-from conftest import load_npz
+import os
+
+from conftest import GOLDEN, load_npz
 from oracle import model_ref as M
 from oracle import ops_ref as R
 from oracle.tiny_models import TINY, make_prompts, make_weights
@@ -273,16 +275,39 @@ def test_full_vocabulary_draw_follows_the_softmax():
     assert out[0] == 9 and out[1] == 40 and 0 <= out[2] < 64
 
 
-def test_blocked_cumsum_is_a_cumulative_sum():
+def test_kept_sets_match_the_hf_warpers():
+    """The oracle's kept set against what HF transformers' TopKLogitsWarper / TopPLogitsWarper keep
+    (tests/golden/sampling_kept_hf.npz, written by oracle/gen_golden.py): flat rows whose nucleus is
+    far larger than 1024 tokens, peaked rows, top_k of 1 / beyond 1024 / the whole vocabulary, tied rows
+    (top-k keeps every token tied with the k-th), the Llama-3 vocabulary -- the same set up to which of
+    the equal logits at the cut are taken (kept_sets_agree)."""
+    from oracle.sampling_cases import CASES, kept_sets_agree, row_of
+    z = np.load(os.path.join(GOLDEN, "sampling_kept_hf.npz"))
+    assert sorted(z.files) == sorted(CASES)
+    sizes = {}
+    for name, (V, kind, t, k, p) in CASES.items():
+        row = row_of(name)
+        hf = np.unpackbits(z[name])[:V].astype(bool)
+        ours = R.sample_kept_mask(row, t, k, p)
+        assert kept_sets_agree(row, hf, ours), name
+        sizes[name] = int(ours.sum())
+        if 0 < k < V:                                        # top-k keeps at least k and every tie with the k-th
+            assert ours.sum() >= min(k, V) or p < 1
+    assert sizes["flat_nucleus_beyond_1024"] > 10000 and sizes["tied_topk100_keeps_every_tie"] > 100
+    assert sizes["peaked_topk1"] == 1 and sizes["llama3_vocab_flat_topp"] > 100000
+
+
+def test_integer_masses_make_the_cut_independent_of_summation_order():
     rng = np.random.default_rng(13)
-    for k in (1, 2, 15, 16, 17, 50, 1000, 1024):
-        w = rng.random(k).astype(np.float32) ** 4
-        c = R.blocked_cumsum(w)
-        want = np.cumsum(w.astype(np.float64))
-        assert c.dtype == np.float32 and c.shape == (k,)
-        assert np.abs(c - want).max() <= 2e-6 * want[-1] + 1e-30
-        assert (np.diff(c) >= 0).all()                     # never decreasing: the inverse-CDF search relies on it
-    assert R.blocked_cumsum(np.zeros(7, np.float32)).tolist() == [0.0] * 7
+    row = R.round_to((rng.standard_normal(5000) * 2).astype(np.float32), "bfloat16")
+    m = R.sample_mass(row, row.max(), np.float32(0.9))
+    assert m.dtype == np.uint64 and int(m.max()) == 1 << 40 and (m <= np.uint64(1 << 40)).all()
+    perm = rng.permutation(5000)
+    assert int(m.sum()) == int(m[perm].sum()) == sum(int(v) for v in m)
+    assert R.mass_threshold(0.0, 12345) == 1 and R.mass_threshold(0.5, 10) == 5 and R.mass_threshold(0.9, 10 ** 15 + 1) == 899999976158143          # float32(0.9) = 0.89999998
+    # -inf logits weigh nothing, the maximum weighs 2^40, even when it is +inf
+    assert R.sample_mass(np.asarray([-np.inf, 3.0], np.float32), 3.0, 1.0).tolist() == [0, 1 << 40]
+    assert R.sample_mass(np.asarray([np.inf, 3.0], np.float32), np.inf, 1.0).tolist() == [1 << 40, 0]
 
 
 def test_top_p_and_top_k_cut_the_candidates():

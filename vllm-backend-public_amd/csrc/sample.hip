@@ -155,33 +155,35 @@ __global__ void argmax_key_to_index_kernel(int64_t* __restrict__ out, const int6
 
 
 // ---------------------------------------------------------------------------
-// Random sampling: temperature, top-k (k <= 1024), top-p, one 1024-thread
-// workgroup per row.  Every arithmetic step is plain fp32 in a fixed order
-// (contraction off, polynomial exp and ln, sequential cumulative sum), so the
-// result is a pure function of (logits, parameters, seed, step) and equals the
-// CPU restatement bit for bit.  Three kinds of row:
+// Random sampling: temperature, top-k (any k), top-p (over the whole vocabulary), one
+// 1024-thread workgroup per row.  Every arithmetic step is plain fp32 in a fixed order
+// (contraction off, polynomial exp and ln) or exact 64-bit integer arithmetic (the
+// probability masses), so the result is a pure function of (logits, parameters, seed,
+// step) and equals the CPU restatement bit for bit.  Three kinds of row:
 //   temperature <= 0      the greedy token (one pass, the argmax key)
-//   no cut (top_k <= 0 and top_p >= 1)
+//   no cut (top_k <= 0 or >= vocab, and top_p >= 1)
 //                         Gumbel-max over the whole row (one pass)
-//   a cut                 the k best (logit desc, index asc), k <= 1024:
-//     1. one pass keeps every thread's two largest keys (registers); two 8-bit radix
-//        passes over those 2048 keys (LDS histogram) give the upper 16 bits of their
-//        k-th largest: a threshold t that at least k logits reach and, for logits
-//        without a pathological layout, only a few more than k do
-//     2. a second pass appends every logit >= t to an LDS list (<= 4096 entries)
-//        and a bitonic sort of the list puts the k best in front, in order.
-//        A list that overflows (huge ties, adversarial layouts) takes the exact
-//        4-pass radix select instead (LDS histogram of 8 key bits a pass, ordered
-//        placement of the ties at the threshold, sort of the 1024)
-//     3. w_i = exp((l_i - l_0) / t); cumulative sum in a fixed blocked order (64
-//        blocks of 16) by one wave; top-p cut; one uniform from a counter hash of
-//        (seed, step) picks the token by inverse CDF
+//   a cut                 the kept set as the published samplers define it (see sample_mass
+//                         below), then Gumbel-max over the kept set.  Two ways to the set:
+//     list  1. one pass keeps every thread's two largest logits (registers); two 8-bit radix
+//              passes over those 2048 keys (LDS histogram) give the upper 16 bits of their
+//              R-th largest (R = top_k, or 1024 without one): a threshold that at least R
+//              logits reach and, for logits without a pathological layout, only a few more do
+//           2. a second pass appends every logit >= it to an LDS list (<= 4096 entries) and,
+//              for a row without top-k, adds up the mass of the whole row; a bitonic sort
+//              orders the list (logit desc, index asc); running sums of the masses; the
+//              prefix that reaches the top-p threshold is the kept set
+//     exact    when top_k exceeds 1024, the list overflows (huge ties, adversarial layouts)
+//              or the nucleus reaches past the list (flat distributions): radix selection
+//              straight from the row, by count for top-k and by mass for top-p (sample_exact)
+//   Both ways find the same set (integer masses: no rounding), so which one ran cannot be
+//   told from the result.
 // The streaming passes read the row (vocab * 2 or 4 bytes, L2-resident after the
 // first) with 16-byte loads and touch LDS only for the few survivors.
 // ---------------------------------------------------------------------------
 constexpr int kSampleThreads = 1024;
-constexpr int kSampleKMax = 1024;
-constexpr int kSampleCap = 4096;     // candidates at or above the threshold guess that LDS holds
+constexpr int kSampleGuessRank = 1024;   // the LDS list is built around the row's 1024 largest logits (or its top_k, if smaller)
+constexpr int kSampleCap = 4096;         // candidates at or above the threshold guess that LDS holds (4 a thread)
 
 // NaN sorts on top, as in argmax_key: a row that holds a NaN yields the index of its first NaN
 // from greedy and from random sampling alike
@@ -454,44 +456,210 @@ __device__ __forceinline__ unsigned long long sample_full_vocab(const void* __re
   return best;
 }
 
-// The exact top-k by radix select straight from the row, for rows whose candidate list does not
-// fit LDS: leaves the k best composites, sorted, in comp[0, k).  `need` keys equal to the k-th
-// largest key T are taken, lowest indices first (ordered placement with wave ballots over
-// wave-contiguous index ranges).
-template <int LDT>
-__device__ __forceinline__ void select_by_radix(const void* base, int vocab, int k, unsigned long long* comp,
-                                                int* hist, int* eq_base, int* sh) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint32_t prefix = 0u, mask = 0u;
-  int need = k;
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    for_each_logit<LDT>(base, vocab, [&](float f, int) {
-      const uint32_t key = sample_key(f);
-      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
-    });
-    __syncthreads();
-    if (wave == 0) radix_pick(hist, need, &sh[0], &sh[1]);
-    __syncthreads();
-    prefix |= static_cast<uint32_t>(sh[0]) << shift;
-    mask |= 255u << shift;
-    need = sh[1];
-    __syncthreads();
-  }
-  const uint32_t T = prefix;
-  const int n_gt = k - need;
+// ---- the kept set of a row with a cut, as the published samplers define it (top-k, then top-p
+// over what top-k kept, both on logits / temperature):
+//   top-k (0 < k < vocab)  keeps every token whose logit reaches the k-th largest logit (ties at
+//                          that value all stay)
+//   top-p (p < 1)          orders the survivors by (logit descending, index ascending) and keeps
+//                          the shortest prefix whose probability mass reaches p of theirs (the
+//                          token that crosses p included; never fewer than one)
+// Probability masses are exact integers: F_i = floor(exp_det((l_i - l_max) / t) * 2^40), sums in 64
+// bits -- no rounding, so no dependence on the order of additions, and the two ways below of
+// finding the prefix agree to the token.  The threshold is P = max(1, ceil(double(p) * double(Z))),
+// Z the mass of the top-k survivors; the prefix ends at the first token whose running sum
+// reaches P.  The token is then drawn from the kept set in the Gumbel-max form (see
+// sample_full_vocab): argmax over the kept i of l_i / t - ln(-ln(u_i)), one uniform per (seed, step,
+// token index) -- the same draw whichever way the set was found.
+__device__ __forceinline__ unsigned long long sample_mass(float l, float l0, float temp) {
+#pragma clang fp contract(off)
+  float z = (l - l0) / temp;
+  if (l == l0) z = 0.0f;                     // also the row maximum itself when it is +inf
+  if (z != z) z = -INFINITY;
+  const float w = exp_det(z);
+  return static_cast<unsigned long long>(w * 1099511627776.0f);   // 2^40: exact scaling, then truncation
+}
 
+__device__ __forceinline__ unsigned long long mass_threshold(float top_p, unsigned long long total) {
+  const double pz = static_cast<double>(top_p) * static_cast<double>(total);
+  const unsigned long long P = static_cast<unsigned long long>(ceil(pz));
+  return P < 1ull ? 1ull : P;
+}
+
+__device__ __forceinline__ unsigned long long gumbel_key(float l, uint32_t index, float temp, uint32_t row_hash) {
+#pragma clang fp contract(off)
+  const float u = sample_uniform_at(row_hash, index);
+  const float a = -ln_det(u);
+  const float g = ln_det(a);
+  const float scaled = l / temp;
+  const float score = scaled - g;
+  return argmax_key(score, index);
+}
+
+// By wave 0: the largest digit d of a 256-bin histogram of 64-bit weights (counts or masses) whose
+// bins >= d hold at least `need`, and how much of `need` bin d itself has to supply.  Lane l owns
+// bins 4l .. 4l+3.  total_out (may be null): the sum of all bins.
+__device__ __forceinline__ void radix_pick64(const unsigned long long* hist, unsigned long long need, int* digit,
+                                             unsigned long long* rem, unsigned long long* bin_mass) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long h4[4], s = 0ull;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h4[j] = hist[4 * lane + j];
+    s += h4[j];
+  }
+  unsigned long long suf = s;                   // weight in the bins of lanes >= this one
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long t = __shfl_down(suf, off, 64);
+    if (lane + off < 64) suf += t;
+  }
+  unsigned long long run = suf - s;
+  int best = -1;
+  unsigned long long left = 0ull, mass = 0ull;
+#pragma unroll
+  for (int j = 3; j >= 0; --j) {
+    if (best < 0 && run + h4[j] >= need) {
+      best = 4 * lane + j;
+      left = need - run;
+      mass = h4[j];
+    }
+    run += h4[j];
+  }
+  // the highest lane with a hit wins
+  const unsigned long long any = __ballot(best >= 0);
+  const int win = any != 0ull ? 63 - __builtin_clzll(any) : -1;
+  if (lane == (win < 0 ? 0 : win)) {
+    *digit = win < 0 ? 0 : best;
+    *rem = win < 0 ? need : left;
+    *bin_mass = win < 0 ? 0ull : mass;
+  }
+}
+
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// The exact kept set straight from the row, for rows whose candidates do not fit the LDS list
+// (top_k beyond the list, a nucleus that reaches past it, huge ties): radix selection over the
+// 32-bit order-preserving keys, 8 bits a pass -- by COUNT for the k-th largest key Tk, then by
+// MASS among the keys >= Tk for the key Tp at which the running mass reaches the threshold -- and
+// the number m of tokens with key == Tp that the prefix still takes (lowest indices first).  Then
+// one ordered pass draws by Gumbel-max from {key > Tp} and the first m of {key == Tp}.
+// Returns the winning 64-bit key in thread 0.
+template <int LDT>
+__device__ __forceinline__ unsigned long long sample_exact(const void* base, int vocab, int K1, float tp, float temp,
+                                                           float l0, uint32_t row_hash, unsigned long long* hist,
+                                                           unsigned long long* part, int* eq_base, int* shi,
+                                                           unsigned long long* shl) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // A 16-bit logit widened to fp32 has zero low bits (bf16: 16, fp16: 13), so the low bits of its key
+  // follow from the sign -- zeros for a key with the top bit set, ones otherwise: the last passes of
+  // a selection over such a row have nothing to decide and are skipped (bf16: two of four, fp16: one).
+  constexpr int kLastShift = LDT == MI355_BF16 ? 16 : LDT == MI355_F16 ? 8 : 0;
+  auto low_bits = [](uint32_t prefix) -> uint32_t {
+    return (prefix & 0x80000000u) ? 0u : ((1u << kLastShift) - 1u);
+  };
+  // One histogram add per run of equal digits inside a 16-byte vector (a row's neighbours mostly share
+  // their leading key bits): the LDS serialises adds to one bin, and at the first level that is most of a pass.
+  auto add_runs = [&](const uint32_t (&dig)[8], const unsigned long long (&val)[8], int nf) {
+    unsigned long long acc = 0ull;
+    uint32_t cur = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < nf && dig[j] != 0xFFFFFFFFu) {
+        if (dig[j] != cur) {
+          if (cur != 0xFFFFFFFFu && acc != 0ull) atomicAdd(&hist[cur], acc);
+          cur = dig[j];
+          acc = 0ull;
+        }
+        acc += val[j];
+      }
+    }
+    if (cur != 0xFFFFFFFFu && acc != 0ull) atomicAdd(&hist[cur], acc);
+  };
+  uint32_t Tk = 0u;
+  if (K1 > 0) {
+    uint32_t prefix = 0u, mask = 0u;
+    unsigned long long need = static_cast<unsigned long long>(K1);
+    for (int shift = 24; shift >= kLastShift; shift -= 8) {
+      if (tid < 256) hist[tid] = 0ull;
+      __syncthreads();
+      for_each_vector<LDT, 2>(base, vocab, [&](const float (&f)[8], int nf, int) {
+        uint32_t dig[8];
+        unsigned long long val[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t key = sample_key(f[j]);
+          dig[j] = (key & mask) == prefix ? (key >> shift) & 255u : 0xFFFFFFFFu;
+          val[j] = 1ull;
+        }
+        add_runs(dig, val, nf);
+      });
+      __syncthreads();
+      if (wave == 0) radix_pick64(hist, need, &shi[0], &shl[0], &shl[1]);
+      __syncthreads();
+      prefix |= static_cast<uint32_t>(shi[0]) << shift;
+      mask |= 255u << shift;
+      need = shl[0];
+      __syncthreads();
+    }
+    Tk = prefix | (kLastShift ? low_bits(prefix) : 0u);
+  }
+  uint32_t Tp = Tk;
+  unsigned long long take = ~0ull;             // tokens with key == Tp that stay (all of them unless top-p cuts inside the tie)
+  if (tp < 1.0f) {
+    uint32_t prefix = 0u, mask = 0u;
+    unsigned long long need = 0ull;
+    for (int shift = 24; shift >= kLastShift; shift -= 8) {
+      if (tid < 256) hist[tid] = 0ull;
+      __syncthreads();
+      for_each_vector<LDT, 2>(base, vocab, [&](const float (&f)[8], int nf, int) {
+        uint32_t dig[8];
+        unsigned long long val[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t key = sample_key(f[j]);
+          const bool in = key >= Tk && (key & mask) == prefix;
+          dig[j] = in ? (key >> shift) & 255u : 0xFFFFFFFFu;
+          val[j] = in && j < nf ? sample_mass(f[j], l0, temp) : 0ull;
+        }
+        add_runs(dig, val, nf);
+      });
+      __syncthreads();
+      if (shift == 24) {                         // the first level's histogram holds the whole mass Z of the top-k survivors
+        if (wave == 0) {
+          unsigned long long t = hist[4 * lane] + hist[4 * lane + 1] + hist[4 * lane + 2] + hist[4 * lane + 3];
+          t = wave_sum64(t);
+          if (lane == 0) shl[2] = mass_threshold(tp, t);
+        }
+        __syncthreads();
+        need = shl[2];
+      }
+      if (wave == 0) radix_pick64(hist, need, &shi[0], &shl[0], &shl[1]);
+      __syncthreads();
+      prefix |= static_cast<uint32_t>(shi[0]) << shift;
+      mask |= 255u << shift;
+      need = shl[0];
+      __syncthreads();
+    }
+    Tp = prefix | (kLastShift ? low_bits(prefix) : 0u);
+    const unsigned long long Fp = sample_mass(key_to_logit(Tp), l0, temp);
+    take = Fp > 0ull ? (need + Fp - 1ull) / Fp : ~0ull;     // need >= 1; every token with key == Tp weighs Fp
+  }
+  // ordered pass: waves own contiguous index ranges, so a token's rank among the key == Tp tokens is
+  // the count in the ranges before its wave's plus the ballot bits below its lane
   const int R = ((vocab + (kSampleThreads / 64) - 1) / (kSampleThreads / 64) + 63) / 64 * 64;
   const int r0 = wave * R, r1 = min(vocab, r0 + R);
   int eq_count = 0;
-  for (int i0 = r0; i0 < r1; i0 += 64) {
-    const int i = i0 + lane;
-    const bool eq = i < r1 && sample_key(load_logit<LDT>(base, i)) == T;
-    eq_count += __popcll(__ballot(eq));
+  if (take != ~0ull) {
+    for (int i0 = r0; i0 < r1; i0 += 64) {
+      const int i = i0 + lane;
+      const bool eq = i < r1 && sample_key(load_logit<LDT>(base, i)) == Tp;
+      eq_count += __popcll(__ballot(eq));
+    }
   }
-  if (tid == 0) sh[2] = 0;
-  for (int i = tid; i < kSampleKMax; i += kSampleThreads) comp[i] = 0ull;
   if (lane == 0) eq_base[wave + 1] = eq_count;
   __syncthreads();
   if (tid == 0) {
@@ -499,28 +667,25 @@ __device__ __forceinline__ void select_by_radix(const void* base, int vocab, int
     for (int w = 0; w < kSampleThreads / 64; ++w) eq_base[w + 1] += eq_base[w];
   }
   __syncthreads();
-  int eq_run = eq_base[wave];
+  unsigned long long eq_run = static_cast<unsigned long long>(eq_base[wave]);
+  unsigned long long best = 0ull;
   for (int i0 = r0; i0 < r1; i0 += 64) {
     const int i = i0 + lane;
+    float f = 0.f;
     uint32_t key = 0u;
-    bool gt = false, eq = false;
     if (i < r1) {
-      key = sample_key(load_logit<LDT>(base, i));
-      gt = key > T;
-      eq = key == T;
+      f = load_logit<LDT>(base, i);
+      key = sample_key(f);
     }
+    const bool eq = i < r1 && key == Tp;
     const unsigned long long eqm = __ballot(eq);
-    const unsigned long long cv = (static_cast<unsigned long long>(key) << 32) |
-                                  static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<uint32_t>(i));
-    if (gt) comp[atomicAdd(&sh[2], 1)] = cv;
-    if (eq) {
-      const int rank = eq_run + __popcll(eqm & ((1ull << lane) - 1ull));
-      if (rank < need) comp[n_gt + rank] = cv;
-    }
-    eq_run += __popcll(eqm);
+    bool kept = i < r1 && key > Tp;
+    if (eq) kept = take == ~0ull || eq_run + static_cast<unsigned long long>(__popcll(eqm & ((1ull << lane) - 1ull))) < take;
+    if (kept) best = umax64(best, gumbel_key(f, static_cast<uint32_t>(i), temp, row_hash));
+    eq_run += static_cast<unsigned long long>(__popcll(eqm));
   }
   __syncthreads();
-  bitonic_desc(comp, kSampleKMax);
+  return sample_reduce_max(best, part);
 }
 
 // Rows that need one key only: greedy ones and draws with neither top-k nor top-p.
@@ -550,13 +715,14 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
   const void* base = LDT == MI355_F32
                          ? static_cast<const void*>(static_cast<const float*>(logits) + row * stride)
                          : static_cast<const void*>(static_cast<const uint16_t*>(logits) + row * stride);
-  __shared__ unsigned long long comp[kSampleCap];
-  __shared__ __align__(16) float csum[kSampleKMax];
+  __shared__ unsigned long long comp[kSampleCap];        // candidates: (key << 32) | inverted index
+  __shared__ unsigned long long pre[kSampleCap];         // running sums of their masses
+  __shared__ unsigned long long hist64[256];
   __shared__ unsigned long long part[kSampleThreads / 64];
+  __shared__ unsigned long long shl[6];
   __shared__ int hist[256];
   __shared__ int eq_base[kSampleThreads / 64 + 1];
   __shared__ int sh[4];
-  __shared__ float block_tot[64];
 
   const float temp = MI355_LD(float, temperature, temperature + row);
   int k = MI355_LD(int32_t, top_k, top_k + row);
@@ -582,156 +748,174 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
     return;
   }
   if (blockIdx.y != 0) return;
-  k = (k > 0 && k <= kSampleKMax) ? k : kSampleKMax;
-  k = min(k, vocab);
+  const int K1 = (k > 0 && k < vocab) ? k : 0;          // an active top-k
+  const uint32_t row_hash = sample_hash(seed, step);
 
-  // ---- 1. threshold guess from every thread's two largest keys.  Those 2048 keys are keys of
-  // distinct logits of the row and at least min(vocab, 2048) >= k of them are real (> 0), so at
-  // least k logits of the row reach a value that k of the 2048 reach.
-  // (floats while streaming -- five operations a logit -- keys afterwards.  A NaN is set aside as
-  // -inf and, if the thread met one, reported as the thread's largest key; a thread with fewer
-  // than two logits reports -inf for the missing ones: such stand-ins can only lower the guess.)
+  // ---- 1. one pass: every thread's two largest logits (for the threshold guess), the row maximum,
+  // and the first NaN (a row that holds a NaN yields its index, like the greedy pick)
   float f1 = -INFINITY, f2 = -INFINITY;
-  bool met_nan = false;
-  for_each_logit<LDT>(base, vocab, [&](float f, int) {
-    met_nan |= f != f;
+  uint32_t nan_at = 0xFFFFFFFFu;
+  for_each_logit<LDT>(base, vocab, [&](float f, int i) {
+    if (f != f) nan_at = min(nan_at, static_cast<uint32_t>(i));
     const float g = f != f ? -INFINITY : f;
     f2 = fmaxf(f2, fminf(f1, g));
     f1 = fmaxf(f1, g);
   });
-  const uint32_t m1 = met_nan ? 0xFFFFFFFFu : sample_key(f1);
-  const uint32_t m2 = met_nan ? sample_key(f1) : sample_key(f2);
-  if (tid == 0) sh[3] = 0;
-  // the k-th largest of the 2048 keys, to its upper 16 bits (two 8-bit radix passes in LDS); the
-  // guess is that prefix with the lower bits clear, so at least k of the keys reach it
-  uint32_t guess = 0u;
   {
-    int need = k;
-    for (int shift = 24; shift >= 16; shift -= 8) {
-      if (tid < 256) hist[tid] = 0;
-      __syncthreads();
-      const uint32_t above = shift == 24 ? 0u : 0xFF000000u;
-      if ((m1 & above) == (guess & above)) atomicAdd(&hist[(m1 >> shift) & 255u], 1);
-      if ((m2 & above) == (guess & above)) atomicAdd(&hist[(m2 >> shift) & 255u], 1);
-      __syncthreads();
-      if (wave == 0) radix_pick(hist, need, &sh[0], &sh[1]);
-      __syncthreads();
-      guess |= static_cast<uint32_t>(sh[0]) << shift;
-      need = sh[1];
-    }
-  }
-
-  // ---- 2. every logit at or above the guess goes to the list: one LDS counter bump per lane and
-  // vector that has any (a few thousand at most unless the row is degenerate)
-  // (compared as floats: "not below the guess" holds for every logit whose key reaches it, for a
-  // NaN, and at most for a few denormals more -- the list may only be a superset)
-  const float guess_f = key_to_logit(guess);
-  for_each_vector<LDT, 2>(base, vocab, [&](const float (&f)[8], int nf, int i0) {
-    int hits = 0;
+    // (max logit, inverted min NaN index) in one 64-bit max-reduction
+    unsigned long long both = (static_cast<unsigned long long>(sample_key(f1)) << 32) |
+                              static_cast<unsigned long long>(0xFFFFFFFFu - nan_at);
+    unsigned long long hi = both & 0xFFFFFFFF00000000ull, lo = both & 0xFFFFFFFFull;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) hits += (j < nf && !(f[j] < guess_f)) ? 1 : 0;
-    if (hits != 0) {
-      int pos = atomicAdd(&sh[3], hits);
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (j < nf && !(f[j] < guess_f)) {
-          if (pos < kSampleCap)
-            comp[pos] = (static_cast<unsigned long long>(sample_key(f[j])) << 32) |
-                        static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<uint32_t>(i0 + j));
-          ++pos;
-        }
+    for (int off = 32; off > 0; off >>= 1) {
+      hi = umax64(hi, __shfl_xor(hi, off, 64));
+      lo = umax64(lo, __shfl_xor(lo, off, 64));
     }
-  });
-  __syncthreads();
-  const int n = sh[3];
-  if (n >= k && n <= kSampleCap) {
-    int P = 64;
-    while (P < n) P <<= 1;
-    for (int i = n + tid; i < P; i += kSampleThreads) comp[i] = 0ull;
+    if (lane == 0) part[wave] = hi | lo;
     __syncthreads();
-    bitonic_desc(comp, P);
-  } else {
-    select_by_radix<LDT>(base, vocab, k, comp, hist, eq_base, sh);
+    if (tid == 0) {
+      for (int w = 1; w < kSampleThreads / 64; ++w) {
+        hi = umax64(hi, part[w] & 0xFFFFFFFF00000000ull);
+        lo = umax64(lo, part[w] & 0xFFFFFFFFull);
+      }
+      shl[3] = hi | lo;
+      sh[3] = 0;                                   // list length
+      sh[2] = 0;                                   // ties beyond the k-th entry
+      shl[4] = 0ull;                               // mass of the whole row
+    }
+    __syncthreads();
   }
-
-  // ---- 3. weights, sequential cumulative sum, top-p cut, inverse-CDF pick
-  const uint32_t key0 = static_cast<uint32_t>(comp[0] >> 32);
-  if (key0 == 0xFFFFFFFFu) {                            // a NaN logit: its index, like argmax
-    if (tid == 0)
-      MI355_ST(int64_t, out, out + row, static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(comp[0] & 0xFFFFFFFFull)));
+  const uint32_t first_nan = 0xFFFFFFFFu - static_cast<uint32_t>(shl[3] & 0xFFFFFFFFull);
+  if (first_nan != 0xFFFFFFFFu) {
+    if (tid == 0) MI355_ST(int64_t, out, out + row, static_cast<int64_t>(first_nan));
     return;
   }
-  const float l0 = key_to_logit(key0);
-  {
-    float w = 0.0f;
-    if (tid < k) {
-      const float li = key_to_logit(static_cast<uint32_t>(comp[tid] >> 32));
-      float z = (li - l0) / temp;
-      if (z != z) z = -INFINITY;
-      w = exp_det(z);
-    }
-    csum[tid] = w;                                   // zero beyond k: all 1024 slots take part in the sum
-  }
-  if (tid == 0) {
-    sh[0] = k;             // keep
-    sh[1] = kSampleKMax;   // pick
-  }
-  __syncthreads();
-  // cumulative sum in a fixed blocked order, by wave 0: lane l adds its 16 consecutive weights in
-  // sequence, lane 0 adds the 64 block totals in sequence, c[16 l + j] = offset[l] + local[l][j]
-  if (wave == 0) {
-    float4* c4 = reinterpret_cast<float4*>(csum) + 4 * lane;
-    float4 v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = c4[q];
-    float acc = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      acc = acc + v[q].x;
-      v[q].x = acc;
-      acc = acc + v[q].y;
-      v[q].y = acc;
-      acc = acc + v[q].z;
-      v[q].z = acc;
-      acc = acc + v[q].w;
-      v[q].w = acc;
-    }
-    block_tot[lane] = acc;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) {
-      float run = 0.0f;
-      for (int b = 0; b < 64; ++b) {
-        const float t = block_tot[b];
-        block_tot[b] = run;
-        run = run + t;
+  const float l0 = key_to_logit(static_cast<uint32_t>(shl[3] >> 32));
+  unsigned long long best = 0ull;
+  bool exact = K1 > kSampleGuessRank;                   // the list is built around the 1024 largest: a deeper top-k goes straight to the exact path
+  if (!exact) {
+    // the R-th largest of the 2048 per-thread keys, to its upper 16 bits (two 8-bit radix passes in
+    // LDS), lower bits clear: at least R logits of the row reach it (the 2048 keys are keys of distinct
+    // logits; stand-ins of threads with fewer than two logits are -inf and can only lower the guess)
+    const int Rk = min(K1 > 0 ? K1 : kSampleGuessRank, vocab);
+    const uint32_t m1 = sample_key(f1), m2 = sample_key(f2);
+    uint32_t guess = 0u;
+    {
+      int need = Rk;
+      for (int shift = 24; shift >= 16; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const uint32_t above = shift == 24 ? 0u : 0xFF000000u;
+        if ((m1 & above) == (guess & above)) atomicAdd(&hist[(m1 >> shift) & 255u], 1);
+        if ((m2 & above) == (guess & above)) atomicAdd(&hist[(m2 >> shift) & 255u], 1);
+        __syncthreads();
+        if (wave == 0) radix_pick(hist, need, &sh[0], &sh[1]);
+        __syncthreads();
+        guess |= static_cast<uint32_t>(sh[0]) << shift;
+        need = sh[1];
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const float off = block_tot[lane];
+    // ---- 2. second pass: every logit at or above the guess goes to the LDS list (one counter bump per
+    // lane and vector that has any); a row without top-k also adds up the mass of the WHOLE row, which
+    // is what its top-p threshold is a share of
+    const float guess_f = key_to_logit(guess);
+    unsigned long long zsum = 0ull;
+    for_each_vector<LDT, 2>(base, vocab, [&](const float (&f)[8], int nf, int i0) {
+      int hits = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      v[q].x = off + v[q].x;
-      v[q].y = off + v[q].y;
-      v[q].z = off + v[q].z;
-      v[q].w = off + v[q].w;
-      c4[q] = v[q];
+      for (int j = 0; j < 8; ++j) hits += (j < nf && !(f[j] < guess_f)) ? 1 : 0;
+      if (K1 == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < nf) zsum += sample_mass(f[j], l0, temp);
+      }
+      if (hits != 0) {
+        int pos = atomicAdd(&sh[3], hits);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < nf && !(f[j] < guess_f)) {
+            if (pos < kSampleCap)
+              comp[pos] = (static_cast<unsigned long long>(sample_key(f[j])) << 32) |
+                          static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<uint32_t>(i0 + j));
+            ++pos;
+          }
+      }
+    });
+    if (K1 == 0) {
+      zsum = wave_sum64(zsum);
+      if (lane == 0) atomicAdd(&shl[4], zsum);
+    }
+    __syncthreads();
+    const int n = sh[3];
+    exact = n < Rk || n > kSampleCap;                   // (n < Rk cannot happen; kept as a guard)
+    if (!exact) {
+      int P2 = 64;
+      while (P2 < n) P2 <<= 1;
+      for (int i = n + tid; i < P2; i += kSampleThreads) comp[i] = 0ull;
+      __syncthreads();
+      bitonic_desc(comp, P2);
+      // the top-k survivors: the first K1 entries and every later one tied with the K1-th
+      int kk = n;
+      if (K1 > 0) {
+        const uint32_t key_k = static_cast<uint32_t>(comp[K1 - 1] >> 32);
+        int extra = 0;
+        for (int j = K1 + tid; j < n; j += kSampleThreads) extra += static_cast<uint32_t>(comp[j] >> 32) == key_k ? 1 : 0;
+        if (extra != 0) atomicAdd(&sh[2], extra);
+        __syncthreads();
+        kk = K1 + sh[2];
+      }
+      // masses and their running sums (exact 64-bit integers): thread t owns entries 4t .. 4t+3
+      unsigned long long m4[4], run = 0ull;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = 4 * tid + q;
+        m4[q] = j < kk ? sample_mass(key_to_logit(static_cast<uint32_t>(comp[j] >> 32)), l0, temp) : 0ull;
+        run += m4[q];
+        m4[q] = run;
+      }
+      unsigned long long incl = run;                     // inclusive scan of the threads' totals inside the wave
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+      }
+      if (lane == 63) part[wave] = incl;
+      __syncthreads();
+      unsigned long long before = incl - run;
+      for (int w = 0; w < wave; ++w) before += part[w];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pre[4 * tid + q] = before + m4[q];
+      if (tid == 0) sh[0] = 0x7FFFFFFF;
+      __syncthreads();
+      int keep = kk;
+      if (tp < 1.0f) {
+        const unsigned long long Z = K1 > 0 ? pre[kk - 1] : shl[4];
+        const unsigned long long P = mass_threshold(tp, Z);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = 4 * tid + q;
+          if (j < kk && pre[j] >= P && (j == 0 || pre[j - 1] < P)) atomicMin(&sh[0], j + 1);
+        }
+        __syncthreads();
+        keep = sh[0];
+        exact = keep == 0x7FFFFFFF;                     // the nucleus reaches past the list: the exact path
+      }
+      if (!exact) {
+        for (int j = tid; j < keep; j += kSampleThreads) {
+          const uint32_t idx = 0xFFFFFFFFu - static_cast<uint32_t>(comp[j] & 0xFFFFFFFFull);
+          best = umax64(best, gumbel_key(key_to_logit(static_cast<uint32_t>(comp[j] >> 32)), idx, temp, row_hash));
+        }
+        __syncthreads();
+        best = sample_reduce_max(best, part);
+      }
     }
   }
-  __syncthreads();
-  // first index that reaches the top-p mass / passes the target: a thread reports only a crossing
-  if (tp < 1.0f) {
-    const float thr = tp * csum[k - 1];
-    if (tid < k && csum[tid] >= thr && (tid == 0 || !(csum[tid - 1] >= thr))) atomicMin(&sh[0], tid + 1);
+  if (exact) {
     __syncthreads();
+    best = sample_exact<LDT>(base, vocab, K1, tp, temp, l0, row_hash, hist64, part, eq_base, sh, shl);
   }
-  const int keep = sh[0];
-  const float target = sample_uniform(seed, step) * csum[keep - 1];
-  if (tid < keep && csum[tid] > target && (tid == 0 || !(csum[tid - 1] > target))) atomicMin(&sh[1], tid);
-  __syncthreads();
-  if (tid == 0) {
-    const int pick = min(sh[1], keep - 1);
-    MI355_ST(int64_t, out, out + row, static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(comp[pick] & 0xFFFFFFFFull)));
-  }
+  if (tid == 0)
+    MI355_ST(int64_t, out, out + row, static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(best & 0xFFFFFFFFull)));
 }
 
 }  // namespace mi355

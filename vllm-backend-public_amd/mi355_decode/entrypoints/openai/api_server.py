@@ -249,9 +249,6 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
                 copies = [dataclasses.replace(params, seed=int(params.seed) + j) for j in range(n)]
             else:
                 copies = [params] * n
-            if params.top_k > 1024:
-                raise ValueError("top_k above 1024 is not supported: a top-k or top-p cut keeps at most the 1024 most "
-                                 "likely tokens (top_k <= 0 with top_p = 1 samples the whole vocabulary)")
             for p in prompts:
                 if len(p) + 1 > max_model_len:
                     raise ValueError(f"This model's maximum context length is {max_model_len} tokens; the prompt has "
