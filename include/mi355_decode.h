@@ -395,6 +395,26 @@ int32_t mi355_sample_topk_topp(int64_t* out_ids, const void* logits,
                                const int64_t* steps, void* stream);
 
 /*
+ * The same, told by the caller whether any row of the batch can have an active cut
+ * (temperature > 0 and top_k in (0, vocab) or top_p < 1).  A row whose kept set cannot be
+ * found among its 4096 largest logits (top_k > 1024, a nucleus or a tie reaching further) needs
+ * several passes over the row; with cut_rows != 0 a fixed sequence of follow-up launches
+ * spreads those passes over many workgroups (rows 0 .. 255 of a batch of fewer than 512 rows;
+ * the launches return at once when no row needs them, but cost their launch gaps, a few
+ * microseconds together), with cut_rows == 0 they are left out and such a row, should there be one
+ * after all, is served by its one workgroup.  The tokens are the same either way.
+ * mi355_sample_topk_topp is this with cut_rows = 1.  The follow-up launches keep their
+ * histograms in one scratch area per process and GPU: calls that may overlap on one GPU
+ * (different streams) must pass cut_rows = 0.
+ */
+int32_t mi355_sample_topk_topp_hinted(int64_t* out_ids, const void* logits,
+                                      int64_t logits_stride, int32_t num_rows,
+                                      int32_t vocab, int32_t logits_dtype,
+                                      const float* temperature, const int32_t* top_k,
+                                      const float* top_p, const int64_t* seeds,
+                                      const int64_t* steps, int32_t cut_rows, void* stream);
+
+/*
  * Log-probabilities for the `logprobs` field of POST /v1/completions
  * (benchmark-deployer/docs/deployment/post_run.md:46):
  *   out_lse[b]     = log(sum_v exp(logits[b, v]))            (fp32, fixed-order sum)

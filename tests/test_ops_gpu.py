@@ -813,6 +813,49 @@ def test_sample_whole_vocabulary_nucleus_distribution(ops):
         assert abs((out == t).mean() - qk[t]) < 4 * np.sqrt(qk[t] / n) + 1e-3
 
 
+@pytest.mark.parametrize("ldt", ["float32", "bfloat16", "float16"])
+@pytest.mark.parametrize("B,V", [(3, 128256), (32, 50272), (300, 16384), (40, 4100)])
+def test_sample_rows_beyond_the_candidate_list(ops, ldt, B, V):
+    """Rows whose kept set cannot be found among the 4096 largest logits: a nucleus over a flat row, a deep top-k
+    with and without top-p, a tie over half the row that top-p cuts inside (the first tokens of the tie by index
+    stay, across the column ranges of the follow-up launches), an all-equal row.  The launches that spread such
+    rows over many workgroups, the one-workgroup form (cut_rows=False, and rows 256 .. of a batch) and the oracle
+    agree to the token."""
+    rng = rng_for("sample-beyond", ldt, B, V)
+    lg = R.round_to((rng.standard_normal((B, V)) * 0.7).astype(np.float32), ldt)
+    temperature = rng.choice([0.6, 1.0, 1.7], B).astype(np.float32)
+    top_k = rng.choice([-1, 1500, 4000, V - 1], B).astype(np.int32)
+    top_p = rng.choice([1.0, 0.97, 0.6, 0.2], B).astype(np.float32)
+    lg[0, :] = 1.25                                          # all equal: top-p keeps a prefix of the row by index
+    top_k[0], top_p[0], temperature[0] = -1, 0.5, 1.0
+    lg[1, V // 4: 3 * V // 4] = lg[1].max() + 1.0            # a tie over half the row on top, cut inside by top-p ...
+    top_k[1], top_p[1] = -1, 0.4
+    lg[2, ::2] = np.float32(0.5)                             # ... and one below a few larger logits, straddling a deep top-k
+    top_k[2], top_p[2] = min(4000, V - 1), 0.9
+    if B > 20:
+        lg[5, 100] = np.nan
+        temperature[6] = 0.0
+    seeds = rng.integers(0, 2 ** 62, B).astype(np.int64)
+    tdt = {"float32": torch.float32, **DT}[ldt]
+    wide = torch.zeros(B, (V + 7) // 8 * 8, dtype=tdt, device="cuda")    # rows start on 16-byte boundaries; the row may end anywhere
+    lgd = wide[:, :V]
+    lgd.copy_(torch.from_numpy(lg).to(tdt))
+    args = [torch.from_numpy(a).cuda() for a in (temperature, top_k, top_p, seeds)]
+    for step in (0, 3):
+        steps = np.full(B, step, np.int64) + 5 * np.arange(B)
+        ref = R.sample_topk_topp(lg, temperature, top_k, top_p, seeds, steps)
+        sd = torch.from_numpy(steps).cuda()
+        spread = ops.sample(lgd, *args, sd).cpu().numpy()
+        single = ops.sample(lgd, *args, sd, cut_rows=False).cpu().numpy()
+        np.testing.assert_array_equal(spread, ref)
+        np.testing.assert_array_equal(single, ref)
+    # a second call with other rows flagged than the first: nothing of the first call's scratch leaks
+    top_k2 = np.roll(top_k, 1)
+    ref = R.sample_topk_topp(lg, temperature, top_k2, top_p, seeds, steps)
+    out = ops.sample(lgd, args[0], torch.from_numpy(top_k2).cuda(), args[2], args[3], sd).cpu().numpy()
+    np.testing.assert_array_equal(out, ref)
+
+
 # --------------------------------------------------------------------------- #
 # decode-time linear layer on fragment-tiled weights
 # --------------------------------------------------------------------------- #

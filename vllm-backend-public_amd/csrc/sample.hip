@@ -318,11 +318,20 @@ __device__ __forceinline__ void for_each_logit_in(const void* base, int vocab, i
 // fn(f, n, i0) for every 16-byte vector of the row (n = 4 or 8 logits f[0, n) starting at index
 // i0) and, one by one (n = 1), for the elements after the last whole vector.
 template <int LDT, int UNROLL, typename F>
+__device__ __forceinline__ void for_each_vector_in(const void* base, int vocab, int v0, int v1, bool tail, F&& fn);
+
+template <int LDT, int UNROLL, typename F>
 __device__ __forceinline__ void for_each_vector(const void* base, int vocab, F&& fn) {
+  for_each_vector_in<LDT, UNROLL>(base, vocab, 0, vocab, true, fn);
+}
+
+// The same over the 16-byte vectors [v0, v1) of the row, plus, if `tail`, the elements after the last whole vector.
+template <int LDT, int UNROLL, typename F>
+__device__ __forceinline__ void for_each_vector_in(const void* base, int vocab, int v0, int v1, bool tail, F&& fn) {
   constexpr int PER = LDT == MI355_F32 ? 4 : 8;
-  const int nvec = vocab / PER;
+  const int nvec = min(v1, vocab / PER);
 #pragma unroll UNROLL
-  for (int v = threadIdx.x; v < nvec; v += kSampleThreads) {
+  for (int v = v0 + threadIdx.x; v < nvec; v += kSampleThreads) {
     float f[8];
     if (LDT == MI355_F32) {
       const float4 q = MI355_LD(float4, base, static_cast<const float*>(base) + 4 * v);
@@ -334,10 +343,11 @@ __device__ __forceinline__ void for_each_vector(const void* base, int vocab, F&&
     }
     fn(f, PER, v * PER);
   }
-  for (int i = nvec * PER + threadIdx.x; i < vocab; i += kSampleThreads) {
-    float f[8] = {load_logit<LDT>(base, i), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    fn(f, 1, i);
-  }
+  if (tail)
+    for (int i = vocab / PER * PER + threadIdx.x; i < vocab; i += kSampleThreads) {
+      float f[8] = {load_logit<LDT>(base, i), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      fn(f, 1, i);
+    }
 }
 
 // Workgroup-wide max of the 64-bit keys; thread 0 gets the result.
@@ -541,6 +551,111 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
   return v;
 }
 
+// One 16-byte vector of the row as fp32 (4 logits of an fp32 row, 8 of a 16-bit one).
+template <int LDT>
+__device__ __forceinline__ void load_vector(const void* base, int v, float (&f)[8]) {
+  if (LDT == MI355_F32) {
+    const float4 q = MI355_LD(float4, base, static_cast<const float*>(base) + 4 * v);
+    f[0] = q.x, f[1] = q.y, f[2] = q.z, f[3] = q.w;
+    f[4] = f[5] = f[6] = f[7] = 0.f;
+  } else {
+    const uint4 raw = MI355_LD(uint4, base, static_cast<const uint16_t*>(base) + 8 * v);
+    if (LDT == MI355_BF16) unpack8<BF16>(raw, f); else unpack8<F16>(raw, f);
+  }
+}
+
+// fn(logit, index) for every kept token among the vectors [v_begin, v_end) of the row (and, if `tail`, the
+// elements after the row's last whole vector): kept = key > Tp, or key == Tp and fewer than `take` tokens with
+// that key precede it in index order (take == ~0: all of them stay).  ties_before: such tokens before v_begin.
+// Waves own contiguous runs of vectors and a lane one vector of 64 consecutive ones at a time, so a token's rank
+// among the ties is the count in the waves before + a scan over the lanes + its place inside the vector.
+// eq_base: kSampleThreads / 64 + 1 ints of LDS.  All threads of the workgroup call it.
+template <int LDT, typename F>
+__device__ __forceinline__ void ordered_kept_pass(const void* base, int vocab, int v_begin, int v_end, bool tail,
+                                                  uint32_t Tp, unsigned long long take,
+                                                  unsigned long long ties_before, int* eq_base, F&& fn) {
+  constexpr int PER = LDT == MI355_F32 ? 4 : 8;
+  constexpr int kWaves = kSampleThreads / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  v_end = min(v_end, vocab / PER);
+  v_begin = min(v_begin, v_end);
+  const int VW = (((v_end - v_begin) + kWaves - 1) / kWaves + 63) / 64 * 64;
+  const int w0 = min(v_end, v_begin + wave * VW), w1 = min(v_end, w0 + VW);
+  const bool ranked = take != ~0ull;                 // the same in every thread
+  unsigned long long eq_run = ties_before;
+  if (ranked) {
+    int c = 0;
+    for (int vb = w0; vb < w1; vb += 64) {
+      const int v = vb + lane;
+      if (v < w1) {
+        float f[8];
+        load_vector<LDT>(base, v, f);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) c += sample_key(f[j]) == Tp ? 1 : 0;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if (lane == 0) eq_base[wave + 1] = c;
+    __syncthreads();
+    if (tid == 0) {
+      eq_base[0] = 0;
+      for (int w = 0; w < kWaves; ++w) eq_base[w + 1] += eq_base[w];
+    }
+    __syncthreads();
+    eq_run += static_cast<unsigned long long>(eq_base[wave]);
+  }
+  for (int vb = w0; vb < w1; vb += 64) {
+    const int v = vb + lane;
+    const bool valid = v < w1;
+    float f[8];
+    if (valid) load_vector<LDT>(base, v, f);
+    int excl = 0, total = 0;
+    if (ranked) {
+      int c = 0;
+      if (valid) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) c += sample_key(f[j]) == Tp ? 1 : 0;
+      }
+      int incl = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+      }
+      excl = incl - c;
+      total = __shfl(incl, 63, 64);
+    }
+    if (valid) {
+      unsigned long long rank = eq_run + static_cast<unsigned long long>(excl);
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const uint32_t key = sample_key(f[j]);
+        bool kept = key > Tp;
+        if (key == Tp) {
+          kept = !ranked || rank < take;
+          ++rank;
+        }
+        if (kept) fn(f[j], v * PER + j);
+      }
+    }
+    eq_run += static_cast<unsigned long long>(total);
+  }
+  if (tail && tid == 0) {                              // fewer than PER elements, after every vector of the row
+    unsigned long long rank = ties_before + (ranked ? static_cast<unsigned long long>(eq_base[kWaves]) : 0ull);
+    for (int i = vocab / PER * PER; i < vocab; ++i) {
+      const float f = load_logit<LDT>(base, i);
+      const uint32_t key = sample_key(f);
+      bool kept = key > Tp;
+      if (key == Tp) {
+        kept = !ranked || rank < take;
+        ++rank;
+      }
+      if (kept) fn(f, i);
+    }
+  }
+}
+
 // The exact kept set straight from the row, for rows whose candidates do not fit the LDS list
 // (top_k beyond the list, a nucleus that reaches past it, huge ties): radix selection over the
 // 32-bit order-preserving keys, 8 bits a pass -- by COUNT for the k-th largest key Tk, then by
@@ -648,44 +763,206 @@ __device__ __forceinline__ unsigned long long sample_exact(const void* base, int
     const unsigned long long Fp = sample_mass(key_to_logit(Tp), l0, temp);
     take = Fp > 0ull ? (need + Fp - 1ull) / Fp : ~0ull;     // need >= 1; every token with key == Tp weighs Fp
   }
-  // ordered pass: waves own contiguous index ranges, so a token's rank among the key == Tp tokens is
-  // the count in the ranges before its wave's plus the ballot bits below its lane
-  const int R = ((vocab + (kSampleThreads / 64) - 1) / (kSampleThreads / 64) + 63) / 64 * 64;
-  const int r0 = wave * R, r1 = min(vocab, r0 + R);
-  int eq_count = 0;
-  if (take != ~0ull) {
-    for (int i0 = r0; i0 < r1; i0 += 64) {
-      const int i = i0 + lane;
-      const bool eq = i < r1 && sample_key(load_logit<LDT>(base, i)) == Tp;
-      eq_count += __popcll(__ballot(eq));
-    }
-  }
-  if (lane == 0) eq_base[wave + 1] = eq_count;
-  __syncthreads();
-  if (tid == 0) {
-    eq_base[0] = 0;
-    for (int w = 0; w < kSampleThreads / 64; ++w) eq_base[w + 1] += eq_base[w];
-  }
-  __syncthreads();
-  unsigned long long eq_run = static_cast<unsigned long long>(eq_base[wave]);
   unsigned long long best = 0ull;
-  for (int i0 = r0; i0 < r1; i0 += 64) {
-    const int i = i0 + lane;
-    float f = 0.f;
-    uint32_t key = 0u;
-    if (i < r1) {
-      f = load_logit<LDT>(base, i);
-      key = sample_key(f);
-    }
-    const bool eq = i < r1 && key == Tp;
-    const unsigned long long eqm = __ballot(eq);
-    bool kept = i < r1 && key > Tp;
-    if (eq) kept = take == ~0ull || eq_run + static_cast<unsigned long long>(__popcll(eqm & ((1ull << lane) - 1ull))) < take;
-    if (kept) best = umax64(best, gumbel_key(f, static_cast<uint32_t>(i), temp, row_hash));
-    eq_run += static_cast<unsigned long long>(__popcll(eqm));
-  }
+  ordered_kept_pass<LDT>(base, vocab, 0, vocab, true, Tp, take, 0ull, eq_base, [&](float f, int i) {
+    best = umax64(best, gumbel_key(f, static_cast<uint32_t>(i), temp, row_hash));
+  });
   __syncthreads();
   return sample_reduce_max(best, part);
+}
+
+// ---- the exact path spread over many workgroups.  One workgroup computes exp / ln for a whole row
+// at the pace of ONE CU (a pass over 128256 logits with a mass per logit: ~35 us; a flat row needs
+// five of them); the launch has up to 256.  A row of the cut launch that needs the exact path
+// (and has a slot in the scratch below: the first kExactRows rows) therefore only raises its flag
+// there, and a fixed sequence of follow-up launches does the radix selection with the row cut into
+// column ranges, one workgroup each:
+//   exact_hist_kernel(stage)   stage s < NL: counts per digit of key level s (top-k);
+//                              s >= NL: masses per digit of level s - NL (top-p).  Every
+//                              workgroup first replays the picks of the earlier stages from their
+//                              finished histograms (a few hundred instructions, the same result
+//                              in every workgroup), then adds its range's histogram to the row's
+//                              with 64-bit integer atomics -- exact, so order-free
+//   exact_final_kernel         Gumbel-max over {key > Tp} and the first `take` tokens with
+//                              key == Tp (rank = such tokens in the ranges before, counted from
+//                              the row, + ordered rank inside the range), merged into out[row]
+//                              by a 64-bit atomic max
+// NL = key levels that can differ for the logits' type (sample_exact: 2 / 3 / 4).  The launches
+// always run (a fixed sequence replays from a HIP graph) and return at once for rows whose flag is
+// down.  The scratch is one set per process and GPU: two sampling calls in flight on one GPU at
+// the same time (different streams) would share it -- the engine samples on one stream.
+constexpr int kExactRows = 256;
+constexpr int kExactStages = 8;
+static __device__ unsigned long long g_exact_hist[kExactRows][kExactStages][256];
+static __device__ unsigned int g_exact_flag[kExactRows];
+static __device__ float g_exact_l0[kExactRows];
+
+template <int LDT>
+struct ExactLevels {
+  static constexpr int kLastShift = LDT == MI355_BF16 ? 16 : LDT == MI355_F16 ? 8 : 0;
+  static constexpr int NL = (24 - kLastShift) / 8 + 1;
+  __device__ static uint32_t low_bits(uint32_t prefix) { return (prefix & 0x80000000u) ? 0u : ((1u << kLastShift) - 1u); }
+};
+
+struct ExactState {
+  uint32_t Tk, Tp;               // keys >= Tk survive top-k; Tp: the key at which the top-p prefix ends
+  unsigned long long take;       // tokens with key == Tp that stay (~0: all)
+  uint32_t prefix, mask;         // of the selection in progress (stage replay)
+  unsigned long long need;
+};
+
+// Replays the picks of stages [0, upto) for `row` from the finished histograms; by every thread of
+// wave 0, result broadcast through LDS (shi / shl scratch).  upto = 2 * NL: the full state.
+template <int LDT>
+__device__ __forceinline__ ExactState exact_replay(int row, int upto, int K1, float tp, float temp, float l0, int* shi,
+                                                   unsigned long long* shl) {
+  using L = ExactLevels<LDT>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  ExactState st;
+  st.Tk = 0u, st.Tp = 0u, st.take = ~0ull, st.prefix = 0u, st.mask = 0u, st.need = 0ull;
+  // top-k: stages 0 .. NL-1
+  if (K1 > 0) {
+    st.need = static_cast<unsigned long long>(K1);
+    for (int lvl = 0; lvl < L::NL && lvl < upto; ++lvl) {
+      const int shift = 24 - 8 * lvl;
+      if (wave == 0) radix_pick64(g_exact_hist[row][lvl], st.need, &shi[0], &shl[0], &shl[1]);
+      __syncthreads();
+      st.prefix |= static_cast<uint32_t>(shi[0]) << shift;
+      st.mask |= 255u << shift;
+      st.need = shl[0];
+      __syncthreads();
+    }
+    if (upto >= L::NL) st.Tk = st.prefix | (L::kLastShift ? L::low_bits(st.prefix) : 0u);
+  }
+  st.Tp = st.Tk;
+  if (upto < L::NL) return st;                     // inside the top-k selection
+  // top-p: stages NL .. 2 NL - 1, a fresh selection among the keys >= Tk
+  st.prefix = 0u, st.mask = 0u, st.need = 0ull;
+  if (tp < 1.0f) {
+    for (int lvl = 0; lvl < L::NL && L::NL + lvl < upto; ++lvl) {
+      const int shift = 24 - 8 * lvl;
+      const unsigned long long* h = g_exact_hist[row][L::NL + lvl];
+      if (lvl == 0) {                              // the first level's histogram holds the whole mass Z of the top-k survivors
+        if (wave == 0) {
+          unsigned long long t = h[4 * lane] + h[4 * lane + 1] + h[4 * lane + 2] + h[4 * lane + 3];
+          t = wave_sum64(t);
+          if (lane == 0) shl[2] = mass_threshold(tp, t);
+        }
+        __syncthreads();
+        st.need = shl[2];
+      }
+      if (wave == 0) radix_pick64(h, st.need, &shi[0], &shl[0], &shl[1]);
+      __syncthreads();
+      st.prefix |= static_cast<uint32_t>(shi[0]) << shift;
+      st.mask |= 255u << shift;
+      st.need = shl[0];
+      __syncthreads();
+    }
+    if (upto >= 2 * L::NL) {
+      st.Tp = st.prefix | (L::kLastShift ? L::low_bits(st.prefix) : 0u);
+      const unsigned long long Fp = sample_mass(key_to_logit(st.Tp), l0, temp);
+      st.take = Fp > 0ull ? (st.need + Fp - 1ull) / Fp : ~0ull;
+    }
+  }
+  return st;
+}
+
+template <int LDT>
+__global__ __launch_bounds__(kSampleThreads) void exact_hist_kernel(
+    const void* __restrict__ logits, int64_t stride, int vocab, const float* __restrict__ temperature,
+    const int32_t* __restrict__ top_k, const float* __restrict__ top_p, int chunk_vecs, int stage) {
+  using L = ExactLevels<LDT>;
+  const int row = blockIdx.x;
+  if (row >= kExactRows || g_exact_flag[row] == 0u) return;
+  const int k = MI355_LD(int32_t, top_k, top_k + row);
+  const int K1 = (k > 0 && k < vocab) ? k : 0;
+  const float tp = MI355_LD(float, top_p, top_p + row), temp = MI355_LD(float, temperature, temperature + row);
+  const bool counting = stage < L::NL;
+  if (counting ? K1 == 0 : !(tp < 1.0f)) return;       // this selection is off for the row
+  const float l0 = g_exact_l0[row];
+  __shared__ unsigned long long hist[256];
+  __shared__ int shi[2];
+  __shared__ unsigned long long shl[4];
+  const int tid = threadIdx.x;
+  const ExactState st = exact_replay<LDT>(row, stage, K1, tp, temp, l0, shi, shl);
+  const int shift = 24 - 8 * (counting ? stage : stage - L::NL);
+  if (tid < 256) hist[tid] = 0ull;
+  __syncthreads();
+  const void* base = LDT == MI355_F32 ? static_cast<const void*>(static_cast<const float*>(logits) + row * stride)
+                                      : static_cast<const void*>(static_cast<const uint16_t*>(logits) + row * stride);
+  const int v0 = blockIdx.y * chunk_vecs, v1 = v0 + chunk_vecs;
+  const bool tail = blockIdx.y == gridDim.y - 1;
+  for_each_vector_in<LDT, 2>(base, vocab, v0, v1, tail, [&](const float (&f)[8], int nf, int) {
+    unsigned long long acc = 0ull;
+    uint32_t cur = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < nf) {
+        const uint32_t key = sample_key(f[j]);
+        if (key >= st.Tk && (key & st.mask) == st.prefix) {
+          const uint32_t d = (key >> shift) & 255u;
+          if (d != cur) {
+            if (cur != 0xFFFFFFFFu && acc != 0ull) atomicAdd(&hist[cur], acc);
+            cur = d;
+            acc = 0ull;
+          }
+          acc += counting ? 1ull : sample_mass(f[j], l0, temp);
+        }
+      }
+    }
+    if (cur != 0xFFFFFFFFu && acc != 0ull) atomicAdd(&hist[cur], acc);
+  });
+  __syncthreads();
+  if (tid < 256 && hist[tid] != 0ull) atomicAdd(&g_exact_hist[row][stage][tid], hist[tid]);
+}
+
+template <int LDT>
+__global__ __launch_bounds__(kSampleThreads) void exact_final_kernel(
+    int64_t* __restrict__ out, const void* __restrict__ logits, int64_t stride, int vocab,
+    const float* __restrict__ temperature, const int32_t* __restrict__ top_k, const float* __restrict__ top_p,
+    const int64_t* __restrict__ seeds, const int64_t* __restrict__ steps, int chunk_vecs) {
+  using L = ExactLevels<LDT>;
+  const int row = blockIdx.x;
+  if (row >= kExactRows || g_exact_flag[row] == 0u) return;
+  const int k = MI355_LD(int32_t, top_k, top_k + row);
+  const int K1 = (k > 0 && k < vocab) ? k : 0;
+  const float tp = MI355_LD(float, top_p, top_p + row), temp = MI355_LD(float, temperature, temperature + row);
+  const float l0 = g_exact_l0[row];
+  __shared__ int shi[2];
+  __shared__ unsigned long long shl[4];
+  __shared__ int eq_base[kSampleThreads / 64 + 1];
+  __shared__ unsigned long long part[kSampleThreads / 64];
+  const int tid = threadIdx.x;
+  const ExactState st = exact_replay<LDT>(row, 2 * L::NL, K1, tp, temp, l0, shi, shl);
+  const void* base = LDT == MI355_F32 ? static_cast<const void*>(static_cast<const float*>(logits) + row * stride)
+                                      : static_cast<const void*>(static_cast<const uint16_t*>(logits) + row * stride);
+  // tokens at the cut key in the column ranges before this one (only when top-p cuts inside that tie): counted
+  // here, from the row itself -- a compare per logit, cheaper than a launch of its own that would leave the counts
+  unsigned long long before = 0ull;
+  if (st.take != ~0ull && blockIdx.y != 0) {
+    unsigned int mine = 0u;
+    for_each_vector_in<LDT, 2>(base, vocab, 0, static_cast<int>(blockIdx.y) * chunk_vecs, false,
+                               [&](const float (&f)[8], int nf, int) {
+#pragma unroll
+                                 for (int j = 0; j < 8; ++j) mine += (j < nf && sample_key(f[j]) == st.Tp) ? 1u : 0u;
+                               });
+    unsigned long long w = wave_sum64(static_cast<unsigned long long>(mine));
+    if ((tid & 63) == 0) part[tid >> 6] = w;
+    __syncthreads();
+    for (int q = 0; q < kSampleThreads / 64; ++q) before += part[q];
+    __syncthreads();
+  }
+  const uint32_t row_hash = sample_hash(static_cast<uint64_t>(MI355_LD(int64_t, seeds, seeds + row)),
+                                        static_cast<uint64_t>(MI355_LD(int64_t, steps, steps + row)));
+  unsigned long long best = 0ull;
+  ordered_kept_pass<LDT>(base, vocab, static_cast<int>(blockIdx.y) * chunk_vecs, (static_cast<int>(blockIdx.y) + 1) * chunk_vecs,
+                         blockIdx.y == gridDim.y - 1, st.Tp, st.take, before, eq_base, [&](float f, int i) {
+                           best = umax64(best, gumbel_key(f, static_cast<uint32_t>(i), temp, row_hash));
+                         });
+  __syncthreads();
+  best = sample_reduce_max(best, part);
+  if (tid == 0 && best != 0ull && MI355_OK_AT(out, out + row, 8))
+    atomicMax(reinterpret_cast<unsigned long long*>(out) + row, best);
 }
 
 // Rows that need one key only: greedy ones and draws with neither top-k nor top-p.
@@ -697,8 +974,10 @@ __global__ void sample_finish_kernel(int64_t* __restrict__ out, const float* __r
                                      const int32_t* __restrict__ top_k, const float* __restrict__ top_p, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (!sample_one_key(MI355_LD(float, temperature, temperature + i), MI355_LD(int32_t, top_k, top_k + i),
-                      MI355_LD(float, top_p, top_p + i)))
+  const bool spread = i < kExactRows && g_exact_flag[i] != 0u;      // its token came from the follow-up launches, as a key
+  if (spread) g_exact_flag[i] = 0u;
+  if (!spread && !sample_one_key(MI355_LD(float, temperature, temperature + i), MI355_LD(int32_t, top_k, top_k + i),
+                                 MI355_LD(float, top_p, top_p + i)))
     return;
   const unsigned long long b = static_cast<unsigned long long>(MI355_LD(int64_t, out, out + i));
   MI355_ST(int64_t, out, out + i, static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(b & 0xFFFFFFFFull)));
@@ -708,7 +987,7 @@ template <int LDT>
 __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
     int64_t* __restrict__ out, const void* __restrict__ logits, int64_t stride, int vocab,
     const float* __restrict__ temperature, const int32_t* __restrict__ top_k, const float* __restrict__ top_p,
-    const int64_t* __restrict__ seeds, const int64_t* __restrict__ steps, int chunk_vecs) {
+    const int64_t* __restrict__ seeds, const int64_t* __restrict__ steps, int chunk_vecs, int spread_exact) {
 #pragma clang fp contract(off)
   const int row = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -910,6 +1189,17 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
       }
     }
   }
+  if (exact && row < kExactRows && spread_exact) {
+    // hand the row to the follow-up launches: clear its histograms, leave the row maximum, raise the flag
+    __syncthreads();
+    unsigned long long* h = &g_exact_hist[row][0][0];
+    for (int j = tid; j < kExactStages * 256; j += kSampleThreads) h[j] = 0ull;
+    if (tid == 0) {
+      g_exact_l0[row] = l0;
+      g_exact_flag[row] = 1u;
+    }
+    return;                                             // out[row] stays 0 (cleared by the launcher): the final launch max-merges into it
+  }
   if (exact) {
     __syncthreads();
     best = sample_exact<LDT>(base, vocab, K1, tp, temp, l0, row_hash, hist64, part, eq_base, sh, shl);
@@ -1019,12 +1309,11 @@ extern "C" int32_t mi355_argmax_key_to_index(int64_t* out_ids, const int64_t* ke
   return check_launch(name);
 }
 
-extern "C" int32_t mi355_sample_topk_topp(int64_t* out_ids, const void* logits, int64_t logits_stride,
-                                          int32_t num_rows, int32_t vocab, int32_t logits_dtype,
-                                          const float* temperature, const int32_t* top_k, const float* top_p,
-                                          const int64_t* seeds, const int64_t* steps, void* stream) {
-  using namespace mi355;
-  const char* name = "mi355_sample_topk_topp";
+namespace mi355 {
+static int32_t sample_entry(const char* name, int64_t* out_ids, const void* logits, int64_t logits_stride,
+                            int32_t num_rows, int32_t vocab, int32_t logits_dtype, const float* temperature,
+                            const int32_t* top_k, const float* top_p, const int64_t* seeds, const int64_t* steps,
+                            int32_t cut_rows, void* stream) {
   MI355_REQUIRE(temperature && top_k && top_p && seeds && steps, MI355_ERR_INVALID, "%s: null pointer", name);
   const int32_t rc = check_logits(name, out_ids, logits, logits_stride, num_rows, vocab, logits_dtype, 0);
   if (rc != MI355_OK || num_rows == 0) return rc;
@@ -1039,18 +1328,52 @@ extern "C" int32_t mi355_sample_topk_topp(int64_t* out_ids, const void* logits, 
   const hipError_t cleared = hipMemsetAsync(out_ids, 0, sizeof(int64_t) * num_rows, s);
   MI355_REQUIRE(cleared == hipSuccess, MI355_ERR_LAUNCH, "%s: clearing the keys failed: %s", name, hipGetErrorString(cleared));
   dim3 grid(num_rows, chunks), block(kSampleThreads);
-  if (logits_dtype == MI355_F32)
-    hipLaunchKernelGGL((sample_kernel<MI355_F32>), grid, block, 0, s, out_ids, logits, logits_stride, vocab,
-                       temperature, top_k, top_p, seeds, steps, chunk_vecs);
-  else if (logits_dtype == MI355_BF16)
-    hipLaunchKernelGGL((sample_kernel<MI355_BF16>), grid, block, 0, s, out_ids, logits, logits_stride, vocab,
-                       temperature, top_k, top_p, seeds, steps, chunk_vecs);
-  else
-    hipLaunchKernelGGL((sample_kernel<MI355_F16>), grid, block, 0, s, out_ids, logits, logits_stride, vocab,
-                       temperature, top_k, top_p, seeds, steps, chunk_vecs);
+  // rows that need the exact kept-set search are spread over the launch's column ranges by follow-up launches
+  // (a fixed sequence: they return at once when no row raised its flag); MI355_SAMPLE_SPREAD=0 keeps such rows
+  // in their one workgroup
+  static const int spread = [] {
+    const char* e = getenv("MI355_SAMPLE_SPREAD");
+    return (e != nullptr && e[0] == '0') ? 0 : 1;
+  }();
+  const int spread_exact = spread && cut_rows != 0 && chunks > 1 ? 1 : 0;
+#define MI355_SAMPLE_LAUNCH(LDT)                                                                                      \
+  do {                                                                                                                \
+    hipLaunchKernelGGL((sample_kernel<LDT>), grid, block, 0, s, out_ids, logits, logits_stride, vocab, temperature,    \
+                       top_k, top_p, seeds, steps, chunk_vecs, spread_exact);                                          \
+    if (spread_exact) {                                                                                               \
+      dim3 xgrid(num_rows < kExactRows ? num_rows : kExactRows, chunks);                                              \
+      for (int stage = 0; stage < 2 * ExactLevels<LDT>::NL; ++stage)                                                   \
+        hipLaunchKernelGGL((exact_hist_kernel<LDT>), xgrid, block, 0, s, logits, logits_stride, vocab, temperature,    \
+                           top_k, top_p, chunk_vecs, stage);                                                          \
+      hipLaunchKernelGGL((exact_final_kernel<LDT>), xgrid, block, 0, s, out_ids, logits, logits_stride, vocab,         \
+                         temperature, top_k, top_p, seeds, steps, chunk_vecs);                                         \
+    }                                                                                                                 \
+  } while (0)
+  if (logits_dtype == MI355_F32) MI355_SAMPLE_LAUNCH(MI355_F32);
+  else if (logits_dtype == MI355_BF16) MI355_SAMPLE_LAUNCH(MI355_BF16);
+  else MI355_SAMPLE_LAUNCH(MI355_F16);
+#undef MI355_SAMPLE_LAUNCH
   const int32_t rc2 = check_launch(name);
   if (rc2 != MI355_OK) return rc2;
   hipLaunchKernelGGL(sample_finish_kernel, dim3((num_rows + 255) / 256), dim3(256), 0, s, out_ids, temperature, top_k,
                      top_p, num_rows);
   return check_launch(name);
+}
+}  // namespace mi355
+
+extern "C" int32_t mi355_sample_topk_topp(int64_t* out_ids, const void* logits, int64_t logits_stride,
+                                          int32_t num_rows, int32_t vocab, int32_t logits_dtype,
+                                          const float* temperature, const int32_t* top_k, const float* top_p,
+                                          const int64_t* seeds, const int64_t* steps, void* stream) {
+  return mi355::sample_entry("mi355_sample_topk_topp", out_ids, logits, logits_stride, num_rows, vocab, logits_dtype,
+                             temperature, top_k, top_p, seeds, steps, 1, stream);
+}
+
+extern "C" int32_t mi355_sample_topk_topp_hinted(int64_t* out_ids, const void* logits, int64_t logits_stride,
+                                                 int32_t num_rows, int32_t vocab, int32_t logits_dtype,
+                                                 const float* temperature, const int32_t* top_k, const float* top_p,
+                                                 const int64_t* seeds, const int64_t* steps, int32_t cut_rows,
+                                                 void* stream) {
+  return mi355::sample_entry("mi355_sample_topk_topp_hinted", out_ids, logits, logits_stride, num_rows, vocab,
+                             logits_dtype, temperature, top_k, top_p, seeds, steps, cut_rows, stream);
 }

@@ -82,6 +82,7 @@ def _load() -> ctypes.CDLL:
         "mi355_rope_kv_write_partial": (I32, [P, I64, P, I32, I64, P, P, P, I32, P, P, P, I32, I64, I32, I32, I32,
                                               I32, P]),
         "mi355_sample_topk_topp": (I32, [P, P, I64, I32, I32, I32, P, P, P, P, P, P]),
+        "mi355_sample_topk_topp_hinted": (I32, [P, P, I64, I32, I32, I32, P, P, P, P, P, I32, P]),
         "mi355_allreduce_oneshot_handle_bytes": (I64, []),
         "mi355_allreduce_oneshot_init": (I32, [P, I32, I32, I64, P]),
         "mi355_allreduce_oneshot_connect": (I32, [P, P]),
@@ -109,7 +110,7 @@ EXPORTS = ("mi355_abi_version", "mi355_last_error", "mi355_target_arch",
            "mi355_argmax_chunked", "mi355_embed_rms_norm",
            "mi355_layer_norm", "mi355_fused_add_layer_norm", "mi355_embed_pos_layer_norm", "mi355_relu",
            "mi355_argmax_shard_key", "mi355_argmax_key_to_index",
-           "mi355_linear_decode", "mi355_sample_topk_topp",
+           "mi355_linear_decode", "mi355_sample_topk_topp", "mi355_sample_topk_topp_hinted",
            "mi355_tiled_weight_elems", "mi355_tile_weights", "mi355_untile_weights", "mi355_untile_weights_fp8",
            "mi355_linear_tiled",
            "mi355_fused_add_rms_norm_partial", "mi355_rope_kv_write_partial",

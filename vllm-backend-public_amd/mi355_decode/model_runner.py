@@ -854,19 +854,21 @@ class ModelRunner:
         With `stage` (a decode step) the parameters travel in that staging set's packed pinned
         buffer, one copy; without (a prefill, which waits for its result anyway) array by array."""
         n = logits.shape[0]
+        tk, tpp, tmp = (np.asarray(sampling[k]) for k in ("top_k", "top_p", "temperature"))
+        cut = bool(((tmp > 0) & (((tk > 0) & (tk < logits.shape[1])) | (tpp < 1))).any())   # any row with an active top-k / top-p
         if stage is not None:
             seeds, steps, temp, top_p, top_k = self.h_samp_np[stage]
             seeds[:n], steps[:n] = sampling["seeds"], sampling["steps"]
             temp[:n], top_p[:n], top_k[:n] = sampling["temperature"], sampling["top_p"], sampling["top_k"]
             self.d_samp.copy_(self.h_samp[stage], non_blocking=True)
             d_seeds, d_steps, d_temp, d_top_p, d_top_k = self.d_samp_views
-            ops.sample(logits, d_temp[:n], d_top_k[:n], d_top_p[:n], d_seeds[:n], d_steps[:n], out=out)
+            ops.sample(logits, d_temp[:n], d_top_k[:n], d_top_p[:n], d_seeds[:n], d_steps[:n], out=out, cut_rows=cut)
             return
         dev = self.device
         t = lambda a, dt: torch.from_numpy(a).to(dev, dtype=dt, non_blocking=True)  # noqa: E731
         ops.sample(logits, t(sampling["temperature"], torch.float32), t(sampling["top_k"], torch.int32),
                    t(sampling["top_p"], torch.float32), t(sampling["seeds"], torch.int64),
-                   t(sampling["steps"], torch.int64), out=out)
+                   t(sampling["steps"], torch.int64), out=out, cut_rows=cut)
 
     def _logprobs(self, logits: torch.Tensor, chosen: torch.Tensor, k: int) -> torch.Tensor:
         """[rows, 1 + 2k] float32 on the device: log-probability of the chosen token, then the k

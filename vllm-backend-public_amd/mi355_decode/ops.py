@@ -510,9 +510,10 @@ def linear_decode(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | No
 
 
 def sample(logits: torch.Tensor, temperature: torch.Tensor, top_k: torch.Tensor, top_p: torch.Tensor,
-           seeds: torch.Tensor, steps: torch.Tensor, out: torch.Tensor | None = None):
+           seeds: torch.Tensor, steps: torch.Tensor, out: torch.Tensor | None = None, cut_rows: bool = True):
     """Per-row sampling (greedy where temperature <= 0).  temperature/top_p float32 [B], top_k int32 [B],
-    seeds/steps int64 [B], all on the device."""
+    seeds/steps int64 [B], all on the device.  cut_rows=False: the caller knows that no row has an active
+    top-k / top-p, so the follow-up launches that serve rows with huge kept sets are left out (same tokens)."""
     _dev(logits, "logits")
     if logits.dtype not in _DT:
         raise TypeError(f"logits dtype {logits.dtype} not supported")
@@ -524,9 +525,10 @@ def sample(logits: torch.Tensor, temperature: torch.Tensor, top_k: torch.Tensor,
             raise ValueError(f"{n} must be contiguous {dt} [num_rows]")
     if out is None:
         out = torch.empty(B, dtype=torch.int64, device=logits.device)
-    check(lib.mi355_sample_topk_topp(out.data_ptr(), logits.data_ptr(), _rows(logits, "logits"), B, V,
-                                     _DT[logits.dtype], temperature.data_ptr(), top_k.data_ptr(), top_p.data_ptr(),
-                                     seeds.data_ptr(), steps.data_ptr(), _stream()))
+    check(lib.mi355_sample_topk_topp_hinted(out.data_ptr(), logits.data_ptr(), _rows(logits, "logits"), B, V,
+                                            _DT[logits.dtype], temperature.data_ptr(), top_k.data_ptr(),
+                                            top_p.data_ptr(), seeds.data_ptr(), steps.data_ptr(),
+                                            1 if cut_rows else 0, _stream()))
     return out
 
 
