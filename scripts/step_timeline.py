@@ -37,7 +37,9 @@ def main():
             for r in csv.DictReader(fh):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    marks = [i for i, r in enumerate(rows) if "argmax_kernel" in r[2]]
+    # a step ends with the greedy pick: the key-to-id kernel of the chunked argmax, or the one-launch argmax
+    last = "argmax_finish_kernel" if any("argmax_finish_kernel" in r[2] for r in rows) else "argmax_kernel"
+    marks = [i for i, r in enumerate(rows) if last in r[2]]
     if len(marks) < 3:
         raise SystemExit("fewer than three argmax launches in the trace")
     steps = []
