@@ -556,6 +556,24 @@ def served_path(engine, cfg, a, batch):
                     "parsing on one thread), then the admission window; the rest of TTFT is the prefill step and the "
                     "first SSE event's way back"}
         out["bursts_admitted_whole"] = f"{len(full)} of {a.served_runs}"
+        # the whole way of a burst, client and server stamps on one clock (both read the host's monotonic clock):
+        # medians over the runs whose burst was admitted in one piece, ms
+        stamps = out.pop("stamps", None) or []
+        legs = []
+        for st in stamps:
+            b = next((b for b in full if b[6] is not None and st["submit_first"] <= b[3] <= st["first_token_last"]), None)
+            if b is None:
+                continue
+            legs.append({"client_submits_over": (st["submit_last"] - st["submit_first"]) * 1e3,
+                         "first_submit_to_first_arrival": (b[3] - st["submit_first"]) * 1e3,
+                         "arrivals_over": (b[4] - b[3]) * 1e3, "admission_window": (b[5] - b[4]) * 1e3,
+                         "admitted_to_step_start": (b[7] - b[5]) * 1e3, "prefill_step": (b[6] - b[7]) * 1e3,
+                         "first_tokens_exist_to_first_client_event": (st["first_token_first"] - b[6]) * 1e3,
+                         "to_median_client_event": (st["first_token_p50"] - b[6]) * 1e3,
+                         "to_last_client_event": (st["first_token_last"] - b[6]) * 1e3})
+        if legs:
+            out["ttft_timeline_ms_p50"] = {k: round(statistics.median(l[k] for l in legs), 2) for k in legs[0]}
+    out.pop("stamps", None)
     out["path"] = ("client process -> HTTP/SSE (uvicorn) -> engine thread -> HIP-graph decode steps; tokenizer: "
                    "byte-wise stand-in (no tokenizer.json for synthetic weights), one SSE event per token")
     return out

@@ -83,7 +83,9 @@ async def one_run(url: str, model: str, prompts: List[List[int]], gen: int):
     return {"steady_tok_s": inside / (t_b - t_a) if t_b > t_a else 0.0,
             "ttft_ms_p50": statistics.median(ttft) * 1e3, "ttft_ms_max": max(ttft) * 1e3,
             "decode_tok_s": B * (gen - 1) / (t_last - t_first) if t_last > t_first else 0.0,
-            "wall_s": t_last, "chunks_min": min(r["chunks"] for r in res)}
+            "wall_s": t_last, "chunks_min": min(r["chunks"] for r in res),
+            # absolute stamps (time.perf_counter, the host's monotonic clock: comparable with the server's)
+            "submit_abs": sorted(t0 + r["submit"] for r in res), "first_abs": sorted(t0 + r["first"] for r in res)}
 
 
 async def post_results(results_url: str, payload: dict) -> List[int]:
@@ -121,7 +123,11 @@ def main(argv=None) -> int:
            "ttft_ms_max_p50": round(statistics.median(r["ttft_ms_max"] for r in runs), 2),
            "steady_decode_tok_s_p50": round(statistics.median(r["steady_tok_s"] for r in runs), 1),
            "decode_tok_s_runs": [round(r["decode_tok_s"], 1) for r in runs],
-           "chunks_per_request_min": min(r["chunks_min"] for r in runs)}
+           "chunks_per_request_min": min(r["chunks_min"] for r in runs),
+           "stamps": [{"submit_first": r["submit_abs"][0], "submit_p50": statistics.median(r["submit_abs"]),
+                       "submit_last": r["submit_abs"][-1], "first_token_first": r["first_abs"][0],
+                       "first_token_p50": statistics.median(r["first_abs"]), "first_token_last": r["first_abs"][-1]}
+                      for r in runs]}
     if a.results_url:
         payload = evaluation_payload(a.benchmark_name, out, model_id=a.model, source="mi355-bench-client")
         out["results_post_status"] = asyncio.run(post_results(a.results_url, payload))

@@ -113,7 +113,10 @@ class EngineThread:
         adds = [m.arrival for m in msgs if isinstance(m, _Add)]
         if adds:          # how long the burst took to arrive and how long the engine then waited for more of it
             now = time.perf_counter()
-            self.bursts.append((len(adds), (max(adds) - min(adds)) * 1e3, (now - max(adds)) * 1e3))
+            # + absolute stamps (time.perf_counter: one clock for every process of the host): first and last
+            # arrival, hand-over to the scheduler; _run adds the time the burst's first tokens existed
+            self.bursts.append([len(adds), (max(adds) - min(adds)) * 1e3, (now - max(adds)) * 1e3,
+                                min(adds), max(adds), now, None])
             del self.bursts[:-64]
         return msgs
 
@@ -189,8 +192,13 @@ class EngineThread:
                         eng.abort_request(m.request_id)
                 if not eng.has_unfinished():
                     continue
+                t_step = time.perf_counter()
                 outs: List[RequestOutput] = eng.step()
                 self.steps += 1
+                if self.bursts and self.bursts[-1][6] is None and outs and outs[0].first_token_time is not None \
+                        and outs[0].num_output_tokens == 1:
+                    self.bursts[-1][6] = outs[0].first_token_time      # the step that prefilled the last admitted burst
+                    self.bursts[-1].append(t_step)
                 batch = []
                 for o in outs:
                     self.tokens_out += len(o.new_token_ids)
