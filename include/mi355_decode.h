@@ -428,6 +428,18 @@ int32_t mi355_token_logprobs(float* out_logprob, float* out_lse, const void* log
                              void* stream);
 
 /*
+ * The k most likely tokens of every row, for the `top_logprobs` lists of the completion routes
+ * (benchmark-deployer/docs/deployment/post_run.md:46): out_ids[b, j] / out_vals[b, j], j < k, in
+ * (logit descending, token id ascending) order -- an exact selection, ties to the lower id, a NaN
+ * logit on top as in mi355_argmax.  out_vals holds the logit as fp32, minus lse[b] when `lse`
+ * (mi355_token_logprobs' log-sum-exp) is given, i.e. the log-probability.  1 <= k <= 64; with
+ * k > vocab the tail is (-1, -inf).
+ */
+int32_t mi355_topk_logits(int64_t* out_ids, float* out_vals, const void* logits,
+                          int64_t logits_stride, int32_t num_rows, int32_t vocab,
+                          int32_t logits_dtype, int32_t k, const float* lse, void* stream);
+
+/*
  * Decode-time linear layer  y[M, N] = x[M, K] . W[N, K]^T (+ bias[N]),  M <= 128:
  * the weight matrix is streamed from HBM exactly once (fp32 accumulation on the
  * matrix cores, one rounding of the result).  W row-major [N, K] contiguous;

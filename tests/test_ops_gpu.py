@@ -814,6 +814,39 @@ def test_sample_whole_vocabulary_nucleus_distribution(ops):
 
 
 @pytest.mark.parametrize("ldt", ["float32", "bfloat16", "float16"])
+@pytest.mark.parametrize("B,V,k", [(3, 128256, 20), (8, 1000, 5), (4, 50272, 64), (5, 40, 64), (6, 696, 1)])
+def test_topk_logits(ops, ldt, B, V, k):
+    """The top_logprobs selection: ids and values bit-exact against the oracle (logit descending, id ascending),
+    with a row of ties, a NaN, signed zeros, k beyond the vocabulary, and as log-probabilities."""
+    rng = rng_for("topk-logits", ldt, B, V, k)
+    lg = R.round_to((rng.standard_normal((B, V)) * 2).astype(np.float32), ldt)
+    lg[0, :] = 0.5                                           # all tied: the lowest ids, in order
+    if B > 2:
+        lg[1, V // 3] = np.nan                               # a NaN sorts on top
+        lg[2, : V // 2] = 0.0                                # signed zeros are one value
+        lg[2, 1::2] = -0.0
+        lg[2, V // 2:] = -1.0
+    tdt = {"float32": torch.float32, **DT}[ldt]
+    wide = torch.zeros(B, (V + 7) // 8 * 8, dtype=tdt, device="cuda")
+    lgd = wide[:, :V]
+    lgd.copy_(torch.from_numpy(lg).to(tdt))
+    ids, vals = ops.topk_logits(lgd, k)
+    rid, rval = R.topk_logits(lg, k)
+    np.testing.assert_array_equal(ids.cpu().numpy(), rid)
+    def same(a, b):                                          # bit for bit, NaN payloads aside
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(np.signbit(a) | np.isnan(a), np.signbit(b) | np.isnan(b))
+    same(vals.cpu().numpy(), rval)
+    lse = torch.from_numpy(rng.standard_normal(B).astype(np.float32)).cuda()
+    ids2, lp = ops.topk_logits(lgd, k, lse=lse)
+    rid2, rlp = R.topk_logits(lg, k, lse=lse.cpu().numpy())
+    np.testing.assert_array_equal(ids2.cpu().numpy(), rid2)
+    same(lp.cpu().numpy(), rlp)
+    with pytest.raises(Exception):
+        ops.topk_logits(lgd, 65)
+
+
+@pytest.mark.parametrize("ldt", ["float32", "bfloat16", "float16"])
 @pytest.mark.parametrize("B,V", [(3, 128256), (32, 50272), (300, 16384), (40, 4100)])
 def test_sample_rows_beyond_the_candidate_list(ops, ldt, B, V):
     """Rows whose kept set cannot be found among the 4096 largest logits: a nucleus over a flat row, a deep top-k

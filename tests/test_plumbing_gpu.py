@@ -132,6 +132,11 @@ def test_harness_plumbing_pass(tmp_path, case, tp):
         assert codes == [200, 200]
         assert ("/raw_input", result_pk(payload)) in ResultsStub.stored
         assert ResultsStub.stored[("/standardized_output", result_pk(payload))]["data"]["requests"] == 4
+        if tp > 1:                                    # what the per-turn control broadcast to the workers costs rank 0
+            m = dict(l.rsplit(" ", 1) for l in client.http.get(f"http://127.0.0.1:{port}/metrics").text.splitlines() if l)
+            n, secs = int(m["mi355_control_broadcasts_total"]), float(m["mi355_control_broadcast_seconds_total"])
+            assert n >= 24 and secs > 0
+            print(f"control broadcast (gloo, 2 ranks on this host): {secs / n * 1e6:.1f} us per engine-loop turn over {n} turns")
         log.flush()
         text = open(tmp_path / "server.log").read()
         for r in range(tp):                           # every rank really came up, with the sharding its size implies

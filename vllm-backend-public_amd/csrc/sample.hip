@@ -965,6 +965,90 @@ __global__ __launch_bounds__(kSampleThreads) void exact_final_kernel(
     atomicMax(reinterpret_cast<unsigned long long*>(out) + row, best);
 }
 
+// ---- the k most likely tokens of a row (the `logprobs` / `top_logprobs` lists of the completion routes): an
+// exact selection, in (logit descending, index ascending) order, NaN on top as in the greedy pick.  One workgroup
+// per row: radix selection by count over the order-preserving keys for the k-th largest key (the passes a 16-bit
+// logit cannot differ in are skipped), then the ordered pass of the samplers' exact search, which keeps every key
+// above it and the lowest-indexed of the tokens tied with it, then the k entries rank themselves.
+constexpr int kTopkMax = 64;
+
+template <int LDT>
+__global__ __launch_bounds__(kSampleThreads) void topk_logits_kernel(
+    int64_t* __restrict__ out_ids, float* __restrict__ out_vals, const void* __restrict__ logits, int64_t stride,
+    int vocab, int k, const float* __restrict__ lse) {
+  using L = ExactLevels<LDT>;
+  const int row = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const void* base = LDT == MI355_F32 ? static_cast<const void*>(static_cast<const float*>(logits) + row * stride)
+                                      : static_cast<const void*>(static_cast<const uint16_t*>(logits) + row * stride);
+  __shared__ unsigned long long hist[256];
+  __shared__ int shi[2];
+  __shared__ unsigned long long shl[4];
+  __shared__ int eq_base[kSampleThreads / 64 + 1];
+  __shared__ unsigned long long found[kTopkMax];
+  __shared__ int nfound;
+  const int K = min(k, vocab);
+  uint32_t prefix = 0u, mask = 0u;
+  unsigned long long need = static_cast<unsigned long long>(K);
+  for (int shift = 24; shift >= L::kLastShift; shift -= 8) {
+    if (tid < 256) hist[tid] = 0ull;
+    if (tid == 0) nfound = 0;
+    __syncthreads();
+    for_each_vector<LDT, 2>(base, vocab, [&](const float (&f)[8], int nf, int) {
+      unsigned long long acc = 0ull;             // one LDS add per run of equal digits inside a vector
+      uint32_t cur = 0xFFFFFFFFu;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < nf) {
+          const uint32_t key = sample_key(f[j]);
+          if ((key & mask) == prefix) {
+            const uint32_t d = (key >> shift) & 255u;
+            if (d != cur) {
+              if (cur != 0xFFFFFFFFu) atomicAdd(&hist[cur], acc);
+              cur = d;
+              acc = 0ull;
+            }
+            acc += 1ull;
+          }
+        }
+      }
+      if (cur != 0xFFFFFFFFu) atomicAdd(&hist[cur], acc);
+    });
+    __syncthreads();
+    if (wave == 0) radix_pick64(hist, need, &shi[0], &shl[0], &shl[1]);
+    __syncthreads();
+    prefix |= static_cast<uint32_t>(shi[0]) << shift;
+    mask |= 255u << shift;
+    need = shl[0];
+    __syncthreads();
+  }
+  const uint32_t Tk = prefix | (L::kLastShift ? L::low_bits(prefix) : 0u);
+  // every key above Tk and the first `need` tokens (by index) with key == Tk: K tokens in all
+  ordered_kept_pass<LDT>(base, vocab, 0, vocab, true, Tk, need, 0ull, eq_base, [&](float f, int i) {
+    const int at = atomicAdd(&nfound, 1);
+    if (at < kTopkMax)
+      found[at] = (static_cast<unsigned long long>(sample_key(f)) << 32) |
+                  static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<uint32_t>(i));
+  });
+  __syncthreads();
+  const int n = min(nfound, K);
+  const float sub = lse != nullptr ? MI355_LD(float, lse, lse + row) : 0.f;
+  if (tid < k) {
+    int64_t id = -1;
+    float val = -INFINITY;
+    int rank = tid;
+    if (tid < n) {
+      const unsigned long long mine = found[tid];
+      rank = 0;
+      for (int j = 0; j < n; ++j) rank += found[j] > mine ? 1 : 0;       // entries are distinct (their indices are)
+      id = static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(mine & 0xFFFFFFFFull));
+      val = load_logit<LDT>(base, static_cast<int>(id)) - sub;
+    }
+    MI355_ST(int64_t, out_ids, out_ids + (static_cast<int64_t>(row) * k + rank), id);
+    MI355_ST(float, out_vals, out_vals + (static_cast<int64_t>(row) * k + rank), val);
+  }
+}
+
 // Rows that need one key only: greedy ones and draws with neither top-k nor top-p.
 __device__ __forceinline__ bool sample_one_key(float temp, int top_k, float top_p) {
   return !(temp > 0.0f) || (top_k <= 0 && !(top_p < 1.0f));
@@ -1376,4 +1460,24 @@ extern "C" int32_t mi355_sample_topk_topp_hinted(int64_t* out_ids, const void* l
                                                  void* stream) {
   return mi355::sample_entry("mi355_sample_topk_topp_hinted", out_ids, logits, logits_stride, num_rows, vocab,
                              logits_dtype, temperature, top_k, top_p, seeds, steps, cut_rows, stream);
+}
+
+extern "C" int32_t mi355_topk_logits(int64_t* out_ids, float* out_vals, const void* logits, int64_t logits_stride,
+                                     int32_t num_rows, int32_t vocab, int32_t logits_dtype, int32_t k,
+                                     const float* lse, void* stream) {
+  using namespace mi355;
+  const char* name = "mi355_topk_logits";
+  MI355_REQUIRE(out_vals != nullptr, MI355_ERR_INVALID, "%s: null pointer", name);
+  MI355_REQUIRE(k >= 1 && k <= kTopkMax, MI355_ERR_UNSUPPORTED, "%s: k %d outside [1, %d]", name, k, kTopkMax);
+  const int32_t rc = check_logits(name, out_ids, logits, logits_stride, num_rows, vocab, logits_dtype, 0);
+  if (rc != MI355_OK || num_rows == 0) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid(num_rows), block(kSampleThreads);
+  if (logits_dtype == MI355_F32)
+    hipLaunchKernelGGL((topk_logits_kernel<MI355_F32>), grid, block, 0, s, out_ids, out_vals, logits, logits_stride, vocab, k, lse);
+  else if (logits_dtype == MI355_BF16)
+    hipLaunchKernelGGL((topk_logits_kernel<MI355_BF16>), grid, block, 0, s, out_ids, out_vals, logits, logits_stride, vocab, k, lse);
+  else
+    hipLaunchKernelGGL((topk_logits_kernel<MI355_F16>), grid, block, 0, s, out_ids, out_vals, logits, logits_stride, vocab, k, lse);
+  return check_launch(name);
 }

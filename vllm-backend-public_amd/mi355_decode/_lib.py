@@ -69,6 +69,7 @@ def _load() -> ctypes.CDLL:
         "mi355_untile_weights_fp8": (I32, [P, P, P, I32, I32, I32, I32, P]),
         "mi355_linear_tiled": (I32, [P, I64, P, P, I64, P, P, I32, I32, I32, I32, I32, I32, I32, P]),
         "mi355_token_logprobs": (I32, [P, P, P, I64, I32, I32, I32, P, P]),
+        "mi355_topk_logits": (I32, [P, P, P, I64, I32, I32, I32, I32, P, P]),
         "mi355_tiled_weight_fp8_bytes": (I64, [I32, I32]),
         "mi355_tile_weights_fp8": (I32, [P, P, P, I32, I32, I32, I32, P]),
         "mi355_linear_tiled_w8": (I32, [P, I64, P, P, I64, P, P, P, I32, I32, I32, I32, I32, I32, I32, P]),
@@ -117,7 +118,7 @@ EXPORTS = ("mi355_abi_version", "mi355_last_error", "mi355_target_arch",
            "mi355_linear_tiled_fused", "mi355_paged_attn_decode_fused",
            "mi355_tiled_weight_fp8_bytes", "mi355_tile_weights_fp8", "mi355_linear_tiled_w8",
            "mi355_quant_rows_fp8", "mi355_linear_tiled_w8a8",
-           "mi355_token_logprobs",
+           "mi355_token_logprobs", "mi355_topk_logits",
            "mi355_allreduce_oneshot_handle_bytes", "mi355_allreduce_oneshot_init", "mi355_allreduce_oneshot_connect",
            "mi355_allreduce_oneshot_run", "mi355_allreduce_oneshot_run_slabs", "mi355_allreduce_oneshot_status",
            "mi355_allreduce_oneshot_status_async", "mi355_allreduce_oneshot_destroy")

@@ -147,6 +147,9 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
         lines = [f"mi355_engine_steps_total {engine_thread.steps}",
                  f"mi355_generation_tokens_total {engine_thread.tokens_out}",
                  f"mi355_uptime_seconds {time.time() - engine_thread.started:.1f}"]
+        if engine_thread.exchanges:                              # tensor parallel: rank 0's per-turn control broadcast to the workers
+            lines += [f"mi355_control_broadcasts_total {engine_thread.exchanges}",
+                      f"mi355_control_broadcast_seconds_total {engine_thread.exchange_s:.6f}"]
         if served_dtype is not None:
             lines += [f'mi355_served_dtype{{dtype="{served_dtype}",requested="{requested_dtype}"}} 1',
                       f"mi355_dtype_downgraded {int(dtype_downgraded)}"]

@@ -872,13 +872,13 @@ class ModelRunner:
 
     def _logprobs(self, logits: torch.Tensor, chosen: torch.Tensor, k: int) -> torch.Tensor:
         """[rows, 1 + 2k] float32 on the device: log-probability of the chosen token, then the k
-        most likely token ids (as floats: exact below 2^24) and their log-probabilities.  The
-        log-sum-exp is the HIP kernel's; picking the top k is a selection, not arithmetic."""
+        most likely token ids (as floats: exact below 2^24) and their log-probabilities (most likely first,
+        ties to the lower id)."""
         lp, lse = ops.token_logprobs(logits, chosen)
         cols = [lp[:, None]]
         if k > 0:
-            topv, topi = torch.topk(logits.float(), k, dim=1)
-            cols += [topi.float(), topv - lse[:, None]]
+            topi, topv = ops.topk_logits(logits, k, lse=lse)
+            cols += [topi.float(), topv]
         return torch.cat(cols, dim=1)
 
     @staticmethod

@@ -489,6 +489,26 @@ def token_logprobs(logits: torch.Tensor, token_ids: torch.Tensor):
     return lp, lse
 
 
+TOPK_MAX = 64
+
+
+def topk_logits(logits: torch.Tensor, k: int, lse: torch.Tensor | None = None):
+    """(token ids int64 [rows, k], values float32 [rows, k]) of the k largest logits of every row, most likely
+    first, ties to the lower id; with `lse` (float32 [rows]) the values are log-probabilities."""
+    _dev(logits, "logits")
+    ldt = _DT.get(logits.dtype)
+    if ldt is None or logits.dim() != 2 or logits.stride(1) != 1:
+        raise TypeError("logits must be a 2-D bf16/fp16/fp32 tensor with unit column stride")
+    B, V = logits.shape
+    if lse is not None and (lse.dtype != torch.float32 or lse.numel() != B or not lse.is_contiguous() or not lse.is_cuda):
+        raise ValueError("lse must be contiguous float32 [rows] on the device")
+    ids = torch.empty((B, k), dtype=torch.int64, device=logits.device)
+    vals = torch.empty((B, k), dtype=torch.float32, device=logits.device)
+    check(lib.mi355_topk_logits(ids.data_ptr(), vals.data_ptr(), logits.data_ptr(), _rows(logits, "logits"), B, V, ldt,
+                                int(k), lse.data_ptr() if lse is not None else 0, _stream()))
+    return ids, vals
+
+
 def linear_decode(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None,
                   out: torch.Tensor | None = None, k_slices: int = 0):
     """y = x @ weight.T (+ bias) for decode batches (M <= 128): weights streamed once."""

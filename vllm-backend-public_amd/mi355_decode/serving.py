@@ -56,6 +56,8 @@ class EngineThread:
         self.admission_cap = float(os.environ.get("MI355_ADMISSION_CAP_MS", "20.0")) * 1e-3
         self.bursts = []                     # (requests, arrival spread ms, wait after the last arrival ms) of recent admissions
         self.steps = 0
+        self.exchanges = 0                   # control broadcasts of a tensor-parallel server (one per loop turn) ...
+        self.exchange_s = 0.0                # ... and the time rank 0 spent in them
         self.tokens_out = 0
         self.started = time.time()
 
@@ -177,7 +179,11 @@ class EngineThread:
                 msgs = self._collect(block=not eng.has_unfinished()) if self.rank == 0 else []
                 if self.stop_flag:
                     msgs.append(None)
-                msgs = self._exchange(msgs)
+                if self.control_group is not None:
+                    t_x = time.perf_counter()
+                    msgs = self._exchange(msgs)
+                    self.exchanges += 1
+                    self.exchange_s += time.perf_counter() - t_x
                 if any(m is None for m in msgs):
                     break
                 for m in msgs:
