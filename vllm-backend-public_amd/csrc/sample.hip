@@ -1075,6 +1075,9 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
 #pragma clang fp contract(off)
   const int row = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // a flag an aborted call may have left up must not reach this call's follow-up launches (the same thread
+  // raises it again further down if this row needs them)
+  if (blockIdx.y == 0 && tid == 0 && row < kExactRows) g_exact_flag[row] = 0u;
   const void* base = LDT == MI355_F32
                          ? static_cast<const void*>(static_cast<const float*>(logits) + row * stride)
                          : static_cast<const void*>(static_cast<const uint16_t*>(logits) + row * stride);
