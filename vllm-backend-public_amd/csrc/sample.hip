@@ -551,6 +551,31 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
   return v;
 }
 
+// for_each_vector that stops early: `go()` is asked before every vector of a thread (the tail elements are
+// visited only if it still says yes).
+template <int LDT, typename G, typename F>
+__device__ __forceinline__ void for_each_vector_while(const void* base, int vocab, G&& go, F&& fn) {
+  constexpr int PER = LDT == MI355_F32 ? 4 : 8;
+  const int nvec = vocab / PER;
+  for (int v = threadIdx.x; v < nvec && go(); v += kSampleThreads) {
+    float f[8];
+    if (LDT == MI355_F32) {
+      const float4 q = MI355_LD(float4, base, static_cast<const float*>(base) + 4 * v);
+      f[0] = q.x, f[1] = q.y, f[2] = q.z, f[3] = q.w;
+      f[4] = f[5] = f[6] = f[7] = 0.f;
+    } else {
+      const uint4 raw = MI355_LD(uint4, base, static_cast<const uint16_t*>(base) + 8 * v);
+      if (LDT == MI355_BF16) unpack8<BF16>(raw, f); else unpack8<F16>(raw, f);
+    }
+    fn(f, PER, v * PER);
+  }
+  if (go())
+    for (int i = nvec * PER + threadIdx.x; i < vocab; i += kSampleThreads) {
+      float f[8] = {load_logit<LDT>(base, i), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      fn(f, 1, i);
+    }
+}
+
 // One 16-byte vector of the row as fp32 (4 logits of an fp32 row, 8 of a 16-bit one).
 template <int LDT>
 __device__ __forceinline__ void load_vector(const void* base, int v, float (&f)[8]) {
@@ -811,8 +836,37 @@ struct ExactState {
   unsigned long long need;
 };
 
-// Replays the picks of stages [0, upto) for `row` from the finished histograms; by every thread of
-// wave 0, result broadcast through LDS (shi / shl scratch).  upto = 2 * NL: the full state.
+// radix_pick64 on bins already in registers (lane l holds bins 4l .. 4l+3), result in every lane.
+__device__ __forceinline__ void radix_pick_regs(const unsigned long long (&h4)[4], unsigned long long need, int& digit,
+                                                unsigned long long& rem) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long s = h4[0] + h4[1] + h4[2] + h4[3];
+  unsigned long long suf = s;                   // weight in the bins of lanes >= this one
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long t = __shfl_down(suf, off, 64);
+    if (lane + off < 64) suf += t;
+  }
+  unsigned long long run = suf - s, left = 0ull;
+  int best = -1;
+#pragma unroll
+  for (int j = 3; j >= 0; --j) {
+    if (best < 0 && run + h4[j] >= need) {
+      best = 4 * lane + j;
+      left = need - run;
+    }
+    run += h4[j];
+  }
+  const unsigned long long any = __ballot(best >= 0);
+  const int win = any != 0ull ? 63 - __builtin_clzll(any) : 0;      // the highest lane with a hit wins
+  digit = any != 0ull ? __shfl(best, win, 64) : 0;
+  rem = any != 0ull ? __shfl(left, win, 64) : need;
+}
+
+// Replays the picks of stages [0, upto) for `row` from the finished histograms.  Wave 0 does it alone: it asks
+// for every histogram it will need at once (one memory round trip instead of one per level, each followed by two
+// workgroup barriers -- a third of the follow-up launches' time), picks level after level with shuffles only and
+// hands the state to the workgroup through LDS (shi / shl scratch).  upto = 2 * NL: the full state.
 template <int LDT>
 __device__ __forceinline__ ExactState exact_replay(int row, int upto, int K1, float tp, float temp, float l0, int* shi,
                                                    unsigned long long* shl) {
@@ -820,50 +874,67 @@ __device__ __forceinline__ ExactState exact_replay(int row, int upto, int K1, fl
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   ExactState st;
   st.Tk = 0u, st.Tp = 0u, st.take = ~0ull, st.prefix = 0u, st.mask = 0u, st.need = 0ull;
-  // top-k: stages 0 .. NL-1
-  if (K1 > 0) {
-    st.need = static_cast<unsigned long long>(K1);
-    for (int lvl = 0; lvl < L::NL && lvl < upto; ++lvl) {
-      const int shift = 24 - 8 * lvl;
-      if (wave == 0) radix_pick64(g_exact_hist[row][lvl], st.need, &shi[0], &shl[0], &shl[1]);
-      __syncthreads();
-      st.prefix |= static_cast<uint32_t>(shi[0]) << shift;
-      st.mask |= 255u << shift;
-      st.need = shl[0];
-      __syncthreads();
+  if (wave == 0) {
+    unsigned long long h[2 * L::NL][4];
+#pragma unroll
+    for (int s_ = 0; s_ < 2 * L::NL; ++s_) {
+      const bool on = s_ < upto && (s_ < L::NL ? K1 > 0 : tp < 1.0f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) h[s_][j] = on ? g_exact_hist[row][s_][4 * lane + j] : 0ull;
     }
-    if (upto >= L::NL) st.Tk = st.prefix | (L::kLastShift ? L::low_bits(st.prefix) : 0u);
-  }
-  st.Tp = st.Tk;
-  if (upto < L::NL) return st;                     // inside the top-k selection
-  // top-p: stages NL .. 2 NL - 1, a fresh selection among the keys >= Tk
-  st.prefix = 0u, st.mask = 0u, st.need = 0ull;
-  if (tp < 1.0f) {
-    for (int lvl = 0; lvl < L::NL && L::NL + lvl < upto; ++lvl) {
-      const int shift = 24 - 8 * lvl;
-      const unsigned long long* h = g_exact_hist[row][L::NL + lvl];
-      if (lvl == 0) {                              // the first level's histogram holds the whole mass Z of the top-k survivors
-        if (wave == 0) {
-          unsigned long long t = h[4 * lane] + h[4 * lane + 1] + h[4 * lane + 2] + h[4 * lane + 3];
-          t = wave_sum64(t);
-          if (lane == 0) shl[2] = mass_threshold(tp, t);
+    // top-k: stages 0 .. NL-1
+    if (K1 > 0) {
+      st.need = static_cast<unsigned long long>(K1);
+#pragma unroll
+      for (int lvl = 0; lvl < L::NL; ++lvl) {
+        if (lvl < upto) {
+          const int shift = 24 - 8 * lvl;
+          int digit;
+          radix_pick_regs(h[lvl], st.need, digit, st.need);
+          st.prefix |= static_cast<uint32_t>(digit) << shift;
+          st.mask |= 255u << shift;
         }
-        __syncthreads();
-        st.need = shl[2];
       }
-      if (wave == 0) radix_pick64(h, st.need, &shi[0], &shl[0], &shl[1]);
-      __syncthreads();
-      st.prefix |= static_cast<uint32_t>(shi[0]) << shift;
-      st.mask |= 255u << shift;
-      st.need = shl[0];
-      __syncthreads();
+      if (upto >= L::NL) st.Tk = st.prefix | (L::kLastShift ? L::low_bits(st.prefix) : 0u);
     }
-    if (upto >= 2 * L::NL) {
-      st.Tp = st.prefix | (L::kLastShift ? L::low_bits(st.prefix) : 0u);
-      const unsigned long long Fp = sample_mass(key_to_logit(st.Tp), l0, temp);
-      st.take = Fp > 0ull ? (st.need + Fp - 1ull) / Fp : ~0ull;
+    st.Tp = st.Tk;
+    if (upto >= L::NL) {
+      // top-p: stages NL .. 2 NL - 1, a fresh selection among the keys >= Tk
+      st.prefix = 0u, st.mask = 0u, st.need = 0ull;
+      if (tp < 1.0f) {
+#pragma unroll
+        for (int lvl = 0; lvl < L::NL; ++lvl) {
+          if (L::NL + lvl < upto) {
+            const int shift = 24 - 8 * lvl;
+            if (lvl == 0)                          // the first level's histogram holds the whole mass Z of the top-k survivors
+              st.need = mass_threshold(tp, wave_sum64(h[L::NL][0] + h[L::NL][1] + h[L::NL][2] + h[L::NL][3]));
+            int digit;
+            radix_pick_regs(h[L::NL + lvl], st.need, digit, st.need);
+            st.prefix |= static_cast<uint32_t>(digit) << shift;
+            st.mask |= 255u << shift;
+          }
+        }
+        if (upto >= 2 * L::NL) {
+          st.Tp = st.prefix | (L::kLastShift ? L::low_bits(st.prefix) : 0u);
+          const unsigned long long Fp = sample_mass(key_to_logit(st.Tp), l0, temp);
+          st.take = Fp > 0ull ? (st.need + Fp - 1ull) / Fp : ~0ull;
+        }
+      }
+    }
+    if (lane == 0) {
+      shl[0] = st.take;
+      shl[1] = st.need;
+      shl[2] = (static_cast<unsigned long long>(st.Tk) << 32) | st.Tp;
+      shl[3] = (static_cast<unsigned long long>(st.prefix) << 32) | st.mask;
     }
   }
+  __syncthreads();
+  st.take = shl[0];
+  st.need = shl[1];
+  st.Tk = static_cast<uint32_t>(shl[2] >> 32), st.Tp = static_cast<uint32_t>(shl[2] & 0xFFFFFFFFull);
+  st.prefix = static_cast<uint32_t>(shl[3] >> 32), st.mask = static_cast<uint32_t>(shl[3] & 0xFFFFFFFFull);
+  __syncthreads();
+  (void)shi;
   return st;
 }
 
@@ -1186,7 +1257,9 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
     // is what its top-p threshold is a share of
     const float guess_f = key_to_logit(guess);
     unsigned long long zsum = 0ull;
-    for_each_vector<LDT, 2>(base, vocab, [&](const float (&f)[8], int nf, int i0) {
+    // (a flat row overflows the list within its first tenth: the pass stops there, the row goes to the exact search)
+    auto list_fits = [&]() { return *reinterpret_cast<volatile int*>(&sh[3]) <= kSampleCap; };
+    for_each_vector_while<LDT>(base, vocab, list_fits, [&](const float (&f)[8], int nf, int i0) {
       int hits = 0;
 #pragma unroll
       for (int j = 0; j < 8; ++j) hits += (j < nf && !(f[j] < guess_f)) ? 1 : 0;
