@@ -117,13 +117,16 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   typedef unsigned int xvec __attribute__((ext_vector_type(4)));   // native vector: stays in registers
   // xs[NX] holds the slice; with NORM xs[NX] one more vector: the norm weights of this thread's column
   constexpr int NXA = NX + (NORM ? 1 : 0);
-  auto x_issue = [&](xvec (&xs)[NXA], int p) {
+  // live = 0 (wave-uniform): a load nobody will use (the last phase has no next slice, but a load inside a branch
+  // would make the compiler drain the queue at the join): every lane then asks for the SAME 16 bytes -- one
+  // cache request per instruction instead of 64 KB of x per workgroup
+  auto x_issue = [&](xvec (&xs)[NXA], int p, int live) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int v = i * NT + tid;
       const int row = v / (KSL / 8), col = v % (KSL / 8);
-      xs[i] = MI355_LD(xvec, x, x + static_cast<int64_t>(min(row, M - 1)) * x_stride +
-                                    static_cast<int64_t>(p) * KSL + col * 8);
+      xs[i] = MI355_LD(xvec, x, x + (static_cast<int64_t>(min(row, M - 1)) * x_stride + col * 8) * live +
+                                    static_cast<int64_t>(p) * KSL);
     }
     if (NORM)
       xs[NXA - 1] = MI355_LD(xvec, fa.norm_w, fa.norm_w + static_cast<int64_t>(p) * KSL + (tid % (KSL / 8)) * 8);
@@ -159,12 +162,12 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   // W8: fp8 weights, 1 KB blocks of 16 rows x 64 k (a lane's 16 bytes are its 8 elements of two
   // consecutive k-steps), so a group of U k-steps is U/2 loads and half the bytes
   constexpr int LPG = W8 ? U / 2 : U;      // 1 KB loads per register group
-  const uint16_t* wbase = wt + (static_cast<int64_t>(p0) * G * tiles_total + tile) * (LPG * 512) + lane * 8;
+  const uint16_t* wbase = wt + (static_cast<int64_t>(p0) * G * tiles_total + tile) * (LPG * 512);
   const int64_t gstride = static_cast<int64_t>(tiles_total) * (LPG * 512);   // from one k group to the next
   const int groups_total = P * G;
-  auto load_group = [&](uint4 (&wd)[LPG], int g) {  // g clamped: the tail re-loads the last group (never used)
+  auto load_group = [&](uint4 (&wd)[LPG], int g) {  // g clamped: the tail asks for the last group's first 16 bytes (never used)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const uint16_t* p = wbase + min(g, groups_total - 1) * gstride;
+    const uint16_t* p = wbase + min(g, groups_total - 1) * gstride + (g < groups_total ? lane * 8 : 0);
 #pragma unroll
     for (int u = 0; u < LPG; ++u) {
       const u32x4 v = MI355_LDNT(u32x4, wt, p + u * 512);
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
   for (int j = 0; j < D - 1; ++j) load_group(ring[j], j);
   {
     xvec xs0[NXA];
-    x_issue(xs0, p0);
+    x_issue(xs0, p0, 1);
     if (NORM) {
       // 1/rms of every row from the partial sums of squares: 8 threads per row, each adds
       // every 8th part (8 loads in flight at a time), then a fixed-order butterfly
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled_kernel(
       if (q >= P) break;                     // P need not be a multiple of PU
       const bool more = q + 1 < P;
       xvec xs[NXA];                          // lives inside one phase only
-      x_issue(xs, p0 + (more ? q + 1 : q));  // unconditional (the last phase re-loads its own slice, unused)
+      x_issue(xs, p0 + (more ? q + 1 : q), more ? 1 : 0);  // unconditional; the last phase's is one address
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         load_group(ring[(pp * G + g + D - 1) % D], q * G + g + D - 1);
@@ -469,13 +472,13 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled2_kernel(
   constexpr int NXV = ROWS * (KSL / 8);
   constexpr int NX = (NXV + NT - 1) / NT;
   typedef unsigned int xvec __attribute__((ext_vector_type(4)));
-  auto x_issue = [&](xvec (&xs)[NX], int p) {
+  auto x_issue = [&](xvec (&xs)[NX], int p, int live) {   // live = 0: a load nobody uses, one address for all lanes
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int v = NXV % NT == 0 ? i * NT + tid : min(i * NT + tid, NXV - 1);
       const int row = v / (KSL / 8), col = v % (KSL / 8);
-      xs[i] = MI355_LD(xvec, x, x + static_cast<int64_t>(min(row, M - 1)) * x_stride +
-                                    static_cast<int64_t>(p) * KSL + col * 8);
+      xs[i] = MI355_LD(xvec, x, x + (static_cast<int64_t>(min(row, M - 1)) * x_stride + col * 8) * live +
+                                    static_cast<int64_t>(p) * KSL);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -490,12 +493,12 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled2_kernel(
 
   constexpr int LPG = W8 ? U / 2 : U;
   const int64_t gstride = static_cast<int64_t>(tiles_total) * (LPG * 512);
-  const uint16_t* wbase0 = wt + (static_cast<int64_t>(p0) * G * tiles_total + tile0) * (LPG * 512) + lane * 8;
-  const uint16_t* wbase1 = wt + (static_cast<int64_t>(p0) * G * tiles_total + tile1) * (LPG * 512) + lane * 8;
+  const uint16_t* wbase0 = wt + (static_cast<int64_t>(p0) * G * tiles_total + tile0) * (LPG * 512);
+  const uint16_t* wbase1 = wt + (static_cast<int64_t>(p0) * G * tiles_total + tile1) * (LPG * 512);
   const int groups_total = P * G;
-  auto load_group = [&](uint4 (&wd)[TPW][LPG], int g) {
+  auto load_group = [&](uint4 (&wd)[TPW][LPG], int g) {   // beyond the last group: its first 16 bytes for every lane (never used)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const int64_t off = min(g, groups_total - 1) * gstride;
+    const int64_t off = min(g, groups_total - 1) * gstride + (g < groups_total ? lane * 8 : 0);
 #pragma unroll
     for (int u = 0; u < LPG; ++u) {
       const u32x4 v0 = MI355_LDNT(u32x4, wt, wbase0 + off + u * 512);
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled2_kernel(
   for (int j = 0; j < D - 1; ++j) load_group(ring[j], j);
   {
     xvec xs0[NX];
-    x_issue(xs0, p0);
+    x_issue(xs0, p0, 1);
     x_commit(xs0, 0);
   }
   __syncthreads();
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(NW * 64) void linear_tiled2_kernel(
       if (q >= P) break;
       const bool more = q + 1 < P;
       xvec xs[NX];
-      x_issue(xs, p0 + (more ? q + 1 : q));
+      x_issue(xs, p0 + (more ? q + 1 : q), more ? 1 : 0);
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         load_group(ring[(pp * G + g + D - 1) % D], q * G + g + D - 1);
@@ -690,13 +693,13 @@ __global__ __launch_bounds__(512) void linear_tiled_kw_kernel(
 
   constexpr int NX = ROWS * (KSL / 8) / NT;
   typedef unsigned int xvec __attribute__((ext_vector_type(4)));
-  auto x_issue = [&](xvec (&xs)[NX], int p) {
+  auto x_issue = [&](xvec (&xs)[NX], int p, int live) {   // live = 0: a load nobody uses, one address for all lanes
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int v = i * NT + tid;
       const int row = v / (KSL / 8), col = v % (KSL / 8);
-      xs[i] = MI355_LD(xvec, x, x + static_cast<int64_t>(min(row, M - 1)) * x_stride +
-                                    static_cast<int64_t>(p) * KSL + col * 8);
+      xs[i] = MI355_LD(xvec, x, x + (static_cast<int64_t>(min(row, M - 1)) * x_stride + col * 8) * live +
+                                    static_cast<int64_t>(p) * KSL);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -711,13 +714,13 @@ __global__ __launch_bounds__(512) void linear_tiled_kw_kernel(
 
   // weight blocks are ordered [k group][tile][k-step in group]; this wave's ls-th group is group
   // (ls / GL) * G + (ls % GL) * KW + kq of the workgroup's K range
-  const uint16_t* wbase = wt + (static_cast<int64_t>(p0) * G * tiles_total + tile) * (U * 512) + lane * 8;
+  const uint16_t* wbase = wt + (static_cast<int64_t>(p0) * G * tiles_total + tile) * (U * 512);
   const int64_t gstride = static_cast<int64_t>(tiles_total) * (U * 512);
   const int groups_total = P * GL;
-  auto load_group = [&](uint4 (&wd)[U], int ls) {       // ls clamped: the tail re-loads the last group (never used)
+  auto load_group = [&](uint4 (&wd)[U], int ls) {       // ls clamped: the tail asks for the last group's first 16 bytes (never used)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int l = min(ls, groups_total - 1);
-    const uint16_t* p = wbase + ((l / GL) * G + (l % GL) * KW + kq) * gstride;
+    const uint16_t* p = wbase + ((l / GL) * G + (l % GL) * KW + kq) * gstride + (ls < groups_total ? lane * 8 : 0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const u32x4 v = MI355_LDNT(u32x4, wt, p + u * 512);
@@ -744,7 +747,7 @@ __global__ __launch_bounds__(512) void linear_tiled_kw_kernel(
   for (int j = 0; j < D - 1; ++j) load_group(ring[j], j);
   {
     xvec xs0[NX];
-    x_issue(xs0, p0);
+    x_issue(xs0, p0, 1);
     x_commit(xs0, 0);
   }
   __syncthreads();
@@ -755,7 +758,7 @@ __global__ __launch_bounds__(512) void linear_tiled_kw_kernel(
       if (q >= P) break;
       const bool more = q + 1 < P;
       xvec xs[NX];
-      x_issue(xs, p0 + (more ? q + 1 : q));            // unconditional (the last phase re-loads its own slice, unused)
+      x_issue(xs, p0 + (more ? q + 1 : q), more ? 1 : 0);   // unconditional; the last phase's is one address
 #pragma unroll
       for (int lg = 0; lg < GL; ++lg) {
         load_group(ring[(pp * GL + lg + D - 1) % D], q * GL + lg + D - 1);
