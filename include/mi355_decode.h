@@ -505,7 +505,12 @@ int32_t mi355_untile_weights_fp8(void* dst, const void* src_tiled, const float* 
  * and so cannot be split across workgroups; 402 / 404: the same with 512-wide slices (the SwiGLU
  * epilogue needs at most 4 waves per tile, and a wave at least 128 columns of the slice).  Built
  * geometries: M <= 32: 4, 8, 104, 108, 302, 304, 308, 402, 404; M <= 64: 8, 104, 108, 208, 210,
- * 212, 214, 216, 302, 304, 402; beyond 64 rows: 8, 210, 212, 214, 216, 302.  k_groups (at most K / slice)
+ * 212, 214, 216, 302, 304, 402; beyond 64 rows: 8, 210, 212, 214, 216, 302.  tiles_per_wg + 1000 /
+ * + 2000 (epilogues 0-2): rows beyond 64 / 32 run as row blocks of 64 / 32 rows of one launch, each
+ * block by the geometry (and slice width) of that row class -- a wave then reads half / a quarter
+ * of the x fragments from LDS per weight fragment, and the blocks of a column block read the same
+ * weights, once from HBM; for the compute-shaped slices of a tensor-parallel rank at 128 / 256
+ * rows.  k_groups (at most K / slice)
  * splits K over workgroups; the slices are dealt to the groups as evenly as they
  * go, K / slice need not be a multiple of k_groups.
  *   epilogue 0: y = round(sum + bias)                       (k_groups == 1)

@@ -1,0 +1,88 @@
+"""Exploration: the tiled GEMM forms at 128 / 256 rows with the rows cut into blocks of 64 or 32 (MI355_EXP_ROW_BLOCK,
+read once per process) instead of 128, on the slices of a Llama-3-8B TP4 / TP8 rank.  In-graph timing over rotating
+weight copies; every timed form is first checked against torch.mm."""
+import json
+import os
+import sys
+import torch
+sys.path.insert(0, "vllm-backend-public_amd")
+from mi355_decode import ops
+from mi355_decode._lib import Mi355Error
+
+torch.manual_seed(0)
+dev = "cuda"
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+tp = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+rb = int(os.environ.get("MI355_EXP_ROW_BLOCK", "128"))
+H, F, V, nh, nkv, d = 4096, 14336, 128256, 32, 8, 128
+shapes = [("qkv", (nh + 2 * nkv) * d // tp, H), ("o", H, nh * d // tp), ("gate_up", 2 * F // tp, H), ("down", H, F // tp)]
+
+
+def timed(fn, ws, reps):
+    fn(ws[0]); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            for w in ws:
+                fn(w)
+    g.replay(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        g.replay()
+        e.record(); e.synchronize()
+        best = min(best, s.elapsed_time(e) * 1000 / (reps * len(ws)))
+    return best
+
+
+def slice_width(tiles):
+    mb = min(M, rb)
+    mt = 1 if mb <= 16 else 2 if mb <= 32 else 4 if mb <= 64 else 8
+    narrow = tiles in (104, 108, 208, 402, 404)
+    return (512 if narrow else 1024) // (1 if mt <= 2 else mt // 2)
+
+
+for name, N, K in shapes:
+    copies = max(2, int(400e6 // (N * K * 2)) + 1)
+    ws = [torch.empty(N, K, dtype=torch.bfloat16, device=dev).normal_(0, 0.02) for _ in range(copies)]
+    wts = [ops.tile_weights(w) for w in ws]
+    x = torch.randn(M, K, dtype=torch.bfloat16, device=dev)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ref = torch.mm(x.float(), ws[0].float().t())
+    reps = max(1, 64 // copies)
+    t_lib = timed(lambda w: torch.mm(x, w.t(), out=out), ws, reps)
+    part = torch.empty(16, M, N, dtype=torch.float32, device=dev)
+    res = []
+    for tiles in (8, 104, 108, 208, 216, 210, 212, 214, 302, 304, 402, 404):
+        ksl = slice_width(tiles)
+        if K % ksl:
+            continue
+        for groups in (1, 2, 4, 8, 16):
+            if groups > K // ksl:
+                continue
+            wgs = -(-((N + 15) // 16) // ops.tiles_per_workgroup(tiles)) * groups * -(-M // min(M, rb))
+            if not 48 <= wgs <= 2048:
+                continue
+            try:
+                if groups == 1:
+                    call = lambda wt: ops.linear_tiled(x, wt, N, out=out, tiles_per_wg=tiles)
+                    call(wts[0])
+                    got = out.float()
+                else:
+                    call = lambda wt: ops.linear_tiled(x, wt, N, partial=part, tiles_per_wg=tiles, k_groups=groups,
+                                                       epilogue=ops.EPI_PARTIAL)
+                    call(wts[0])
+                    got = part[:groups].sum(0)
+                err = (got - ref).abs().max().item()
+                if not err < 0.05 * ref.abs().max().item() + 0.05:
+                    print(f"  {name} {tiles}/{groups}: WRONG (max err {err:.3f})", flush=True)
+                    continue
+                us = timed(call, wts, reps)
+            except Mi355Error:
+                continue
+            res.append((us, tiles, groups, wgs))
+    res.sort()
+    line = {"rows": M, "tp": tp, "row_block": rb, "proj": name, "N": N, "K": K, "library_us": round(t_lib, 2),
+            "best": [[round(u, 2), t, g, w] for u, t, g, w in res[:6]]}
+    print(json.dumps(line), flush=True)

@@ -1308,6 +1308,76 @@ def test_linear_tiled_129_to_256_rows(ops, dtype, M, N, K, tiles, groups):
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,N,K,tiles,groups", [(128, 1536, 4096, 1008, 8), (128, 4096, 1024, 1108, 4), (128, 7168, 4096, 1214, 4),
+                                                (128, 4096, 3584, 1008, 4), (256, 768, 4096, 1208, 8), (256, 4096, 512, 1302, 1),
+                                                (256, 4096, 512, 2104, 1), (128, 4096, 1024, 2302, 1), (200, 1544, 4096, 1104, 2),
+                                                (100, 1000, 1024, 1210, 2), (65, 320, 1024, 2008, 1), (256, 4096, 1792, 1402, 1),
+                                                (192, 1536, 4096, 2108, 4), (128, 336, 1024, 1304, 1)])
+def test_linear_tiled_row_blocks_of_64_and_32(ops, dtype, M, N, K, tiles, groups):
+    """tiles_per_wg + 1000 / + 2000: the rows of a 65 .. 256-row launch in blocks of 64 / 32, each block by the
+    geometry of that row class.  Store, partial slabs and the slab sum against the fp64 product and the oracle,
+    and every (full enough) block bit-identical to the same rows run as a launch of their own with the base code."""
+    rng = rng_for("tiled-rowblocks-64-32", dtype, M, N, K, tiles)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (N, K), dtype, 0.05)
+    wt, xd = ops.tile_weights(dev(w, dtype)), dev(x, dtype)
+    ref64 = x.astype(np.float64) @ w.astype(np.float64).T
+    tol = _linear_tol(ref64, x, w, K, dtype)
+    rb = ops.row_block_rows(tiles)
+    assert rb == (64 if tiles < 2000 else 32) and ops.tiled_slice_width(M, tiles) == ops.tiled_slice_width(rb, tiles % 1000)
+    if groups == 1:
+        y = host(ops.linear_tiled(xd, wt, N, tiles_per_wg=tiles))
+        assert (np.abs(y - ref64) <= tol).all()
+        assert (y != R.linear(x, w, None, dtype)).mean() <= 0.02
+        for a in range(0, M, rb):
+            if M - a <= rb // 2:                                     # (fewer rows take another geometry: another slice width)
+                continue
+            np.testing.assert_array_equal(host(ops.linear_tiled(xd[a:a + rb].contiguous(), wt, N, tiles_per_wg=tiles % 1000)),
+                                          y[a:a + rb])
+    partd = ops.linear_tiled(xd, wt, N, k_groups=groups, epilogue=ops.EPI_PARTIAL, tiles_per_wg=tiles)
+    part = partd.cpu().numpy()
+    assert part.shape == (groups, M, N)
+    unit = ops.tiled_slice_width(M, tiles)
+    units = K // unit
+    edges = [unit * (g * (units // groups) + min(g, units % groups)) for g in range(groups + 1)]
+    for g in range(groups):
+        ref = x[:, edges[g]:edges[g + 1]].astype(np.float64) @ w[:, edges[g]:edges[g + 1]].astype(np.float64).T
+        np.testing.assert_allclose(part[g], ref, rtol=1e-4, atol=2e-3)
+    y_ref = _slab_sum(part, None, dtype)
+    assert (np.abs(y_ref - ref64) <= tol).all()
+    if N % 8 == 0:
+        ys = ops.sum_slabs(partd, groups, torch.empty(M, N, dtype=DT[dtype], device="cuda"))
+        np.testing.assert_array_equal(host(ys), y_ref)
+
+
+@pytest.mark.parametrize("M,F,K,tiles", [(128, 3584, 4096, 1302), (256, 1792, 4096, 1216), (128, 3584, 4096, 2008),
+                                         (200, 512, 1024, 1104)])
+def test_linear_tiled_row_blocks_swiglu_epilogue(ops, M, F, K, tiles):
+    """The SwiGLU epilogue in row blocks of 64 / 32: bit-identical to the unfused pair of the same form."""
+    dtype = "bfloat16"
+    rng = rng_for("tiled-rowblocks-swiglu", M, F, K, tiles)
+    x, w = grid(rng, (M, K), dtype), grid(rng, (2 * F, K), dtype, 0.05)
+    xd = dev(x, dtype)
+    wt_i = ops.tile_weights(dev(w, dtype), interleave_halves=True)
+    act = host(ops.linear_tiled(xd, wt_i, 2 * F, tiles_per_wg=tiles, epilogue=ops.EPI_SILU_MUL))
+    gu = ops.linear_tiled(xd, ops.tile_weights(dev(w, dtype)), 2 * F, tiles_per_wg=tiles)
+    np.testing.assert_array_equal(act, host(ops.silu_and_mul(gu)))
+    ref = R.silu_and_mul(R.linear(x, w, None, dtype), dtype)
+    assert (act != ref).mean() <= 0.02
+
+
+def test_linear_tiled_row_blocks_reject_fused_forms(ops):
+    from mi355_decode._lib import Mi355Error
+    wt = ops.tile_weights(torch.zeros(64, 1024, dtype=torch.bfloat16, device="cuda"))
+    with pytest.raises(Mi355Error, match="row blocks of 64 / 32"):
+        ops.linear_tiled_fused(torch.zeros(128, 1024, dtype=torch.bfloat16, device="cuda"), wt, 64, tiles_per_wg=1008, k_groups=2,
+                               epilogue=ops.EPI_REDUCE_STORE, counters=torch.zeros(8, dtype=torch.int32, device="cuda"))
+    with pytest.raises(Mi355Error):
+        ops.linear_tiled(torch.zeros(128, 1024, dtype=torch.bfloat16, device="cuda"), wt, 64, tiles_per_wg=3008)
+    with pytest.raises(Mi355Error, match="no kernel"):                # two tiles per wave exist from 33 rows
+        ops.linear_tiled(torch.zeros(128, 1024, dtype=torch.bfloat16, device="cuda"), wt, 64, tiles_per_wg=2216)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 @pytest.mark.parametrize("M,N,S,bias", [(128, 4096, 4, False), (256, 4096, 8, True), (5, 448, 1, True), (33, 1000, 3, False),
                                         (192, 8192, 2, False), (1, 8, 7, False)])
 def test_sum_slabs(ops, dtype, M, N, S, bias):

@@ -14,6 +14,9 @@ KW = {302, 304, 308, 402, 404}        # K split across the waves of a workgroup:
 BUILT = {16: {4, 8, 104, 108} | KW, 32: {4, 8, 104, 108} | KW,
          64: {8, 104, 108, 208, 210, 212, 214, 216, 302, 304, 402}, 128: {8, 210, 212, 214, 216, 302},
          256: {8, 210, 212, 214, 216, 302}}       # two row blocks of the 128-row geometries
+# beyond 64 rows also row blocks of 64 (+ 1000: the 64-row geometries) and of 32 rows (+ 2000: the 32-row ones
+# that exist for epilogues 0-2 on plain x)
+ROW_BLOCKS = {1000 + t for t in BUILT[64]} | {2000 + t for t in (8, 104, 108, 302, 304, 402)}
 
 
 @pytest.mark.parametrize("M", [1, 16, 17, 32, 33, 64, 65, 128, 129, 192, 256])
@@ -27,11 +30,14 @@ def test_candidates_are_built_geometries(M, N, K, split):
         return
     assert cands[0] == plan and len(set(cands)) == len(cands)
     for tiles, groups in cands:
-        assert tiles in BUILT[cls]
+        assert tiles in BUILT[cls] or (M > 64 and tiles in ROW_BLOCKS)
         ksl = ops.tiled_slice_width(M, tiles)
+        assert ksl == ops.tiled_slice_width(min(M, ops.row_block_rows(tiles)), tiles % 1000)
         assert K % ksl == 0 and 1 <= groups <= min(K // ksl, 8)
         assert split or groups == 1
-        assert ops.tiles_per_workgroup(tiles) in ((1, 2, 4) if tiles in KW else (4, 8, 10, 12, 14, 16))
+        assert ops.tiles_per_workgroup(tiles) in ((1, 2, 4) if tiles % 1000 in KW else (4, 8, 10, 12, 14, 16))
+    if M <= 64:
+        assert all(t < 1000 for t, _ in cands)
 
 
 def test_narrow_slices_get_the_k_split_across_waves():
@@ -45,6 +51,12 @@ def test_narrow_slices_get_the_k_split_across_waves():
     assert not {t for t, _ in ops.linear_tiled_candidates(28672, 4096, False, 32, swiglu=True)} & KW
     assert {t for t, _ in ops.linear_tiled_candidates(4096, 7168, False, 64)} & KW == {302, 304, 402}
     assert {t for t, _ in ops.linear_tiled_candidates(7168, 4096, False, 128, swiglu=True)} & KW == {302}
+    # ... and in row blocks of 64 / 32 the forms of those row classes (a TP4 rank at 128 rows)
+    rb = {t for t, _ in ops.linear_tiled_candidates(7168, 4096, False, 128, swiglu=True) if t >= 1000}
+    assert {1302, 1304, 2302, 2304, 1008, 2008} <= rb and 2308 not in rb
+    assert ops.row_block_rows(8) == 128 and ops.row_block_rows(1302) == 64 and ops.row_block_rows(2104) == 32
+    assert ops.tiled_slice_width(128, 1302) == 512 and ops.tiled_slice_width(256, 2104) == 512
+    assert ops.tiles_per_workgroup(1302) == 4 and ops.tiles_per_workgroup(2008) == 8
     assert ops.tiled_slice_width(16, 308) == 1024 and ops.tiled_slice_width(32, 404) == 512
     assert ops.tiled_slice_width(64, 304) == 512 and ops.tiled_slice_width(128, 302) == 256
     assert ops.tiles_per_workgroup(302) == 4 and ops.tiles_per_workgroup(308) == 1

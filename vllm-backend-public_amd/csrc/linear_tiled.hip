@@ -1134,6 +1134,12 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
                                    const FusedArgs& fa, int32_t dtype, void* stream) {
   const bool norm = fa.norm_w != nullptr;
   const bool reduce = epilogue == EPI_REDUCE_STORE || epilogue == EPI_REDUCE_RESID;
+  const int rb_code = tiles_per_wg / 1000;
+  MI355_REQUIRE(tiles_per_wg >= 0 && rb_code <= 2 && (rb_code == 0 || (!norm && !reduce)), MI355_ERR_INVALID,
+                "%s: tiles_per_wg %d: + 1000 / + 2000 (row blocks of 64 / 32) go with epilogues 0-2 on plain x", name,
+                tiles_per_wg);
+  const int rb_rows = rb_code == 1 ? 64 : rb_code == 2 ? 32 : 128;
+  tiles_per_wg %= 1000;
   MI355_REQUIRE(x && w_tiled, MI355_ERR_INVALID, "%s: null pointer", name);
   MI355_REQUIRE(M >= 0 && M <= kMaxRows, MI355_ERR_UNSUPPORTED, "%s: M %d outside [0, %d]", name, M, kMaxRows);
   MI355_REQUIRE(M <= 128 || (!norm && !reduce), MI355_ERR_UNSUPPORTED,
@@ -1152,7 +1158,11 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
   const int nw = two ? (tiles_per_wg - 200) / 2 : tiles_per_wg % 100;
   MI355_REQUIRE(two || kws || ((nw == 4 || nw == 8) && (tiles_per_wg == nw || tiles_per_wg == nw + 100)),
                 MI355_ERR_INVALID, "%s: tiles_per_wg must be 4, 8, 104, 108, 208-216 (even), 302, 304, 308, 402 or 404", name);
-  const int mt = M <= 16 ? 1 : M <= 32 ? 2 : M <= 64 ? 4 : 8;   // beyond 128 rows: row blocks of 128 (gridDim.z)
+  // Rows of a row block (gridDim.z): 128, or with tiles_per_wg + 1000 / + 2000 blocks of 64 / 32 rows, each run
+  // by the kernel form built for that many rows (a wave's fragments of x from LDS per weight fragment halve with
+  // the block; the blocks of a column block read the same weights, once from HBM).
+  const int Mb = min(M, rb_rows);
+  const int mt = Mb <= 16 ? 1 : Mb <= 32 ? 2 : Mb <= 64 ? 4 : 8;
   const int ksl = ((kws ? tiles_per_wg >= 400 : two ? tiles_per_wg == 208 : tiles_per_wg >= 100) ? 512 : 1024) /
                   (mt <= 2 ? 1 : mt / 2);
   MI355_REQUIRE(!kws || (!norm && !reduce && fa.w_scale == nullptr), MI355_ERR_UNSUPPORTED,
@@ -1205,7 +1215,7 @@ static int32_t linear_tiled_launch(const char* name, void* y, int64_t y_stride, 
   if (M == 0) return MI355_OK;
   const int tiles_total = (N + 15) / 16;
   const int tiles_wg = kws ? 8 / (tiles_per_wg % 100) : two ? 2 * nw : nw;
-  dim3 grid((tiles_total + tiles_wg - 1) / tiles_wg, k_groups, (M + 127) / 128);
+  dim3 grid((tiles_total + tiles_wg - 1) / tiles_wg, k_groups, (M + rb_rows - 1) / rb_rows);
   hipStream_t s = static_cast<hipStream_t>(stream);
   auto* yp = static_cast<uint16_t*>(y);
   auto* xp = static_cast<const uint16_t*>(x);

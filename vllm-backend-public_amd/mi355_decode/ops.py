@@ -560,8 +560,15 @@ LINEAR_TILED_MAX_M = 256             # beyond 128 rows: two row blocks of one la
 KW_CODES = (302, 304, 308, 402, 404)   # K split across 2 / 4 / 8 waves of an 8-wave workgroup (4xx: 512-wide x slices)
 
 
+def row_block_rows(tiles_per_wg: int) -> int:
+    """Rows of a row block (one workgroup's rows) for a tiles_per_wg code: 128, + 1000: 64, + 2000: 32."""
+    return (128, 64, 32)[tiles_per_wg // 1000]
+
+
 def tiled_slice_width(M: int, tiles_per_wg: int) -> int:
     """K slice of x a workgroup of linear_tiled stages at a time."""
+    M = min(M, row_block_rows(tiles_per_wg))
+    tiles_per_wg %= 1000
     mt = 1 if M <= 16 else 2 if M <= 32 else 4 if M <= 64 else 8
     narrow = tiles_per_wg in (104, 108, 208, 402, 404)      # 210 .. 216 (two tiles per wave, 5 .. 8 waves) stage the wide slice
     return (512 if narrow else 1024) // (1 if mt <= 2 else mt // 2)
@@ -569,7 +576,8 @@ def tiled_slice_width(M: int, tiles_per_wg: int) -> int:
 
 def tiles_per_workgroup(tiles_per_wg: int) -> int:
     """Weight tiles one workgroup covers for a tiles_per_wg code (208 .. 216: two tiles per wave;
-    30x / 40x: 8 waves, x waves per tile)."""
+    30x / 40x: 8 waves, x waves per tile; + 1000 / + 2000: the same in row blocks of 64 / 32)."""
+    tiles_per_wg %= 1000
     if tiles_per_wg in KW_CODES:
         return 8 // (tiles_per_wg % 100)
     return tiles_per_wg % 100
@@ -617,7 +625,8 @@ def linear_tiled_candidates(N: int, K: int, split_k: bool, M: int = 32, swiglu: 
     two tiles per wave (208 .. 216: 4 .. 8 waves, so that a tile count that 16 per workgroup would
     spread over too few CUs finds a better deal), kept if the launch has between 64 and 1024 workgroups; up to 32
     rows and few tiles also the forms that split K across the waves of a workgroup (`swiglu`: the
-    gate / up pair must share a workgroup, at most 4 waves per tile).  Not
+    gate / up pair must share a workgroup, at most 4 waves per tile); beyond 64 rows also the forms of
+    the 64- and 32-row classes run in row blocks of 64 / 32 (tiles_per_wg + 1000 / + 2000).  Not
     every form exists for every code (fp8 at up to 32 rows: 8 and 104 only): the caller skips a
     candidate the library refuses.  plan_linear_tiled's choice comes first."""
     first = plan_linear_tiled(N, K, split_k, M)
@@ -635,6 +644,21 @@ def linear_tiled_candidates(N: int, K: int, split_k: bool, M: int = 32, swiglu: 
         for g in ((1, 2, 4, 8) if split_k else (1,)):
             if g <= K // ksl and 64 <= wgs * g <= 1024 and (tiles, g) not in out:
                 out.append((tiles, g))
+    # beyond 64 rows: the same forms in row blocks of 64 / 32 rows (tiles_per_wg + 1000 / + 2000)
+    for rb_code, rb, forms in ((1000, 64, (8, 104, 108, 208, 216, 210, 212, 214, 302, 304, 402)),
+                               (2000, 32, (8, 104, 108, 302, 304, 402))):
+        if M <= 64:
+            break
+        blocks = -(-M // rb)
+        for tiles in forms:
+            code = rb_code + tiles
+            ksl = tiled_slice_width(M, code)
+            if K % ksl or (tiles in KW_CODES and ((swiglu and tiles % 100 > 4) or (tiles % 100) * 128 > ksl)):
+                continue
+            wgs = -(-tiles_total // tiles_per_workgroup(code)) * blocks
+            for g in ((1, 2, 4, 8) if split_k else (1,)):
+                if g <= K // ksl and 96 <= wgs * g <= 1024 and (code, g) not in out:
+                    out.append((code, g))
     if tiles_total < 8 * 160:
         # few tiles (a tensor-parallel rank's slice): K split across the waves of a workgroup, the
         # only way to more waves when the output must be 16-bit or gated (no slabs)
