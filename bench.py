@@ -773,7 +773,9 @@ def main():
                                         + (" -- the one-shot kernel's set-up or self-test failed, fell back"
                                            if r_.oneshot_fallbacks else "")),
                           "oneshot_allreduce_fallbacks": r_.oneshot_fallbacks,
-                          "gemm_form": {k: ("tiled" if v else "library") for k, v in r_._mode(batch).items()}}
+                          "gemm_form": {k: ("tiled" if v else "library") for k, v in r_._mode(batch).items()},
+                          # (tiles_per_wg code, K groups) of the tiled forms: + 1000 / + 2000 = row blocks of 64 / 32
+                          "gemm_plan": {k: list(v) for k, v in r_._tiled_plan(r_.bucket_for(batch)).items()}}
 
     # what the job really ran on: ranks the process group saw, its backend, every rank's device
     mine = {"rank": rank, "device": torch.cuda.get_device_name(engine.device), "index": engine.device.index,

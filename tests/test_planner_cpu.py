@@ -14,7 +14,7 @@ KW = {302, 304, 308, 402, 404}        # K split across the waves of a workgroup:
 BUILT = {16: {4, 8, 104, 108} | KW, 32: {4, 8, 104, 108} | KW,
          64: {8, 104, 108, 208, 210, 212, 214, 216, 302, 304, 402}, 128: {8, 210, 212, 214, 216, 302},
          256: {8, 210, 212, 214, 216, 302}}       # two row blocks of the 128-row geometries
-# beyond 64 rows also row blocks of 64 (+ 1000: the 64-row geometries) and of 32 rows (+ 2000: the 32-row ones
+# beyond 64 / 32 rows also row blocks of 64 (+ 1000: the 64-row geometries) / of 32 rows (+ 2000: the 32-row ones
 # that exist for epilogues 0-2 on plain x)
 ROW_BLOCKS = {1000 + t for t in BUILT[64]} | {2000 + t for t in (8, 104, 108, 302, 304, 402)}
 
@@ -30,13 +30,13 @@ def test_candidates_are_built_geometries(M, N, K, split):
         return
     assert cands[0] == plan and len(set(cands)) == len(cands)
     for tiles, groups in cands:
-        assert tiles in BUILT[cls] or (M > 64 and tiles in ROW_BLOCKS)
+        assert tiles in BUILT[cls] or (tiles in ROW_BLOCKS and M > ops.row_block_rows(tiles))
         ksl = ops.tiled_slice_width(M, tiles)
         assert ksl == ops.tiled_slice_width(min(M, ops.row_block_rows(tiles)), tiles % 1000)
         assert K % ksl == 0 and 1 <= groups <= min(K // ksl, 8)
         assert split or groups == 1
         assert ops.tiles_per_workgroup(tiles) in ((1, 2, 4) if tiles % 1000 in KW else (4, 8, 10, 12, 14, 16))
-    if M <= 64:
+    if M <= 32:
         assert all(t < 1000 for t, _ in cands)
 
 

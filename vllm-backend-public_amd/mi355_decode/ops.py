@@ -8,6 +8,8 @@ new tensor (pass ``out=`` to avoid that, e.g. under HIP graph capture).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -625,8 +627,8 @@ def linear_tiled_candidates(N: int, K: int, split_k: bool, M: int = 32, swiglu: 
     two tiles per wave (208 .. 216: 4 .. 8 waves, so that a tile count that 16 per workgroup would
     spread over too few CUs finds a better deal), kept if the launch has between 64 and 1024 workgroups; up to 32
     rows and few tiles also the forms that split K across the waves of a workgroup (`swiglu`: the
-    gate / up pair must share a workgroup, at most 4 waves per tile); beyond 64 rows also the forms of
-    the 64- and 32-row classes run in row blocks of 64 / 32 (tiles_per_wg + 1000 / + 2000).  Not
+    gate / up pair must share a workgroup, at most 4 waves per tile); beyond 64 / 32 rows also the forms of
+    the 64- / 32-row class run in row blocks of 64 / 32 (tiles_per_wg + 1000 / + 2000).  Not
     every form exists for every code (fp8 at up to 32 rows: 8 and 104 only): the caller skips a
     candidate the library refuses.  plan_linear_tiled's choice comes first."""
     first = plan_linear_tiled(N, K, split_k, M)
@@ -644,11 +646,11 @@ def linear_tiled_candidates(N: int, K: int, split_k: bool, M: int = 32, swiglu: 
         for g in ((1, 2, 4, 8) if split_k else (1,)):
             if g <= K // ksl and 64 <= wgs * g <= 1024 and (tiles, g) not in out:
                 out.append((tiles, g))
-    # beyond 64 rows: the same forms in row blocks of 64 / 32 rows (tiles_per_wg + 1000 / + 2000)
+    # beyond 64 / 32 rows: the forms of the 64- / 32-row class in row blocks of 64 / 32 rows (tiles_per_wg + 1000 / + 2000)
     for rb_code, rb, forms in ((1000, 64, (8, 104, 108, 208, 216, 210, 212, 214, 302, 304, 402)),
                                (2000, 32, (8, 104, 108, 302, 304, 402))):
-        if M <= 64:
-            break
+        if M <= rb or os.environ.get("MI355_ROW_BLOCKS", "1") == "0":      # (the switch: for A/B timing)
+            continue
         blocks = -(-M // rb)
         for tiles in forms:
             code = rb_code + tiles
