@@ -1,0 +1,59 @@
+"""Exploration: is the 64-row fp8 gate_up GEMM (Qwen2-7B) held by the memory side or by the CU?  The same launch
+over ONE weight copy (138 MB: served from the 256 MB memory-side cache after the first pass) and over rotating
+copies (from HBM), bf16 beside it, each in the forms the tuner picks."""
+import json
+import sys
+import torch
+sys.path.insert(0, "vllm-backend-public_amd")
+from mi355_decode import ops
+
+torch.manual_seed(0)
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+N, K = 37888, 3584
+
+
+def timed(fn, ws, reps):
+    fn(ws[0]); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            for w in ws:
+                fn(w)
+    g.replay(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); g.replay(); e.record(); e.synchronize()
+        best = min(best, s.elapsed_time(e) * 1000 / (reps * len(ws)))
+    return best
+
+
+x = torch.randn(M, K, dtype=torch.bfloat16, device="cuda")
+out = torch.empty(M, N // 2, dtype=torch.bfloat16, device="cuda")
+ws = [torch.empty(N, K, dtype=torch.bfloat16, device="cuda").normal_(0, 0.02) for _ in range(6)]
+w8 = [ops.tile_weights_fp8(w, interleave_halves=True) for w in ws]
+w16 = [ops.tile_weights(w, interleave_halves=True) for w in ws]
+del ws
+for tiles in (212, 502, 504, 602, 604):
+    row = {"rows": M, "tiles_per_wg": tiles}
+    try:
+        f8 = lambda w: ops.linear_tiled_w8(x, w[0], w[1], N, out=out, tiles_per_wg=tiles, epilogue=ops.EPI_SILU_MUL)
+        f8(w8[0]); ref8 = out.float().clone()
+        ops.linear_tiled_w8(x, w8[0][0], w8[0][1], N, out=out, tiles_per_wg=212, epilogue=ops.EPI_SILU_MUL)
+        row["fp8_mismatch_vs_212"] = round((out.float() != ref8).float().mean().item(), 5)
+        row["fp8_max_diff"] = round((out.float() - ref8).abs().max().item(), 4)
+        row["fp8_cold_us"] = round(timed(f8, w8, 4), 2)
+        row["fp8_hot_us"] = round(timed(f8, w8[:1], 24), 2)
+    except Exception as exc:
+        row["fp8"] = str(exc)[:60]
+    try:
+        f16 = lambda w: ops.linear_tiled(x, w, N, out=out, tiles_per_wg=tiles, epilogue=ops.EPI_SILU_MUL)
+        f16(w16[0]); ref16 = out.float().clone()
+        ops.linear_tiled(x, w16[0], N, out=out, tiles_per_wg=212, epilogue=ops.EPI_SILU_MUL)
+        row["bf16_mismatch_vs_212"] = round((out.float() != ref16).float().mean().item(), 5)
+        row["bf16_max_diff"] = round((out.float() - ref16).abs().max().item(), 4)
+        row["bf16_cold_us"] = round(timed(f16, w16, 4), 2)
+        row["bf16_hot_us"] = round(timed(f16, w16[:1], 24), 2)
+    except Exception as exc:
+        row["bf16"] = str(exc)[:60]
+    print(json.dumps(row), flush=True)

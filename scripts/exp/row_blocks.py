@@ -1,8 +1,8 @@
-"""Exploration: the tiled GEMM forms at 128 / 256 rows with the rows cut into blocks of 64 or 32 (MI355_EXP_ROW_BLOCK,
-read once per process) instead of 128, on the slices of a Llama-3-8B TP4 / TP8 rank.  In-graph timing over rotating
-weight copies; every timed form is first checked against torch.mm."""
+"""Exploration: the tiled GEMM forms at 128 / 256 rows with the rows cut into blocks of 128, 64 or 32
+(tiles_per_wg, + 1000, + 2000; argv[3] = 128 | 64 | 32) on the slices of a Llama-3-8B TP4 / TP8 rank.  In-graph timing
+over rotating weight copies; every timed form is first checked against torch.mm.  (The committed record was taken
+when the block size was still an environment switch of an experimental build; the forms are the same.)"""
 import json
-import os
 import sys
 import torch
 sys.path.insert(0, "vllm-backend-public_amd")
@@ -13,7 +13,8 @@ torch.manual_seed(0)
 dev = "cuda"
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 tp = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-rb = int(os.environ.get("MI355_EXP_ROW_BLOCK", "128"))
+rb = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+CODE = {128: 0, 64: 1000, 32: 2000}[rb]
 H, F, V, nh, nkv, d = 4096, 14336, 128256, 32, 8, 128
 shapes = [("qkv", (nh + 2 * nkv) * d // tp, H), ("o", H, nh * d // tp), ("gate_up", 2 * F // tp, H), ("down", H, F // tp)]
 
@@ -36,13 +37,6 @@ def timed(fn, ws, reps):
     return best
 
 
-def slice_width(tiles):
-    mb = min(M, rb)
-    mt = 1 if mb <= 16 else 2 if mb <= 32 else 4 if mb <= 64 else 8
-    narrow = tiles in (104, 108, 208, 402, 404)
-    return (512 if narrow else 1024) // (1 if mt <= 2 else mt // 2)
-
-
 for name, N, K in shapes:
     copies = max(2, int(400e6 // (N * K * 2)) + 1)
     ws = [torch.empty(N, K, dtype=torch.bfloat16, device=dev).normal_(0, 0.02) for _ in range(copies)]
@@ -55,7 +49,8 @@ for name, N, K in shapes:
     part = torch.empty(16, M, N, dtype=torch.float32, device=dev)
     res = []
     for tiles in (8, 104, 108, 208, 216, 210, 212, 214, 302, 304, 402, 404):
-        ksl = slice_width(tiles)
+        tiles += CODE
+        ksl = ops.tiled_slice_width(M, tiles)
         if K % ksl:
             continue
         for groups in (1, 2, 4, 8, 16):
