@@ -552,6 +552,7 @@ def served_path(engine, cfg, a, batch):
         out["ttft_breakdown_ms_p50"] = {
             "requests_arrive_over": round(statistics.median(b[1] for b in full), 2),
             "engine_waits_for_stragglers": round(statistics.median(b[2] for b in full), 2),
+            "longest_pauses_between_arrivals": [[round(g, 2), round(g2, 2)] for n_, g, g2 in thread.burst_gaps if n_ == batch],
             "note": "server side, per burst admitted in one piece: first to last request handed to the engine (HTTP "
                     "parsing on one thread), then the admission window; the rest of TTFT is the prefill step and the "
                     "first SSE event's way back"}

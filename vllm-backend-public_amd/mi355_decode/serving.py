@@ -55,6 +55,7 @@ class EngineThread:
         self.admission_window = float(os.environ.get("MI355_ADMISSION_WINDOW_MS", "2.0")) * 1e-3
         self.admission_cap = float(os.environ.get("MI355_ADMISSION_CAP_MS", "20.0")) * 1e-3
         self.bursts = []                     # (requests, arrival spread ms, wait after the last arrival ms) of recent admissions
+        self.burst_gaps = []                 # (requests, longest and second longest pause between two arrivals ms) of the same admissions
         self.steps = 0
         self.exchanges = 0                   # control broadcasts of a tensor-parallel server (one per loop turn) ...
         self.exchange_s = 0.0                # ... and the time rank 0 spent in them
@@ -97,7 +98,10 @@ class EngineThread:
         # Admission window: requests of one client burst arrive a fraction of a millisecond apart
         # (now and then more than a millisecond: the HTTP thread shares the interpreter with this
         # one -- with a 1 ms window two of five 32-request bursts were split, which costs the late
-        # half a whole prefill step of latency; 2 ms costs every burst 1 ms);
+        # half a whole prefill step of latency; 2 ms costs every burst 1 ms.  Every 32-request burst
+        # holds two pauses of 1.05-1.5 ms between arrivals -- the server accepting the burst's other
+        # connections before it reads them -- so a shorter window after the first few requests does
+        # not work either: 0.5 ms split 14 of 16 bursts);
         # prefilling each as it lands would stagger the batch over several prefill steps.  While
         # new requests keep arriving within `admission_window` of each other (and for at most
         # `admission_cap` in all) the engine waits for the rest of the burst before it schedules.
@@ -120,6 +124,10 @@ class EngineThread:
             self.bursts.append([len(adds), (max(adds) - min(adds)) * 1e3, (now - max(adds)) * 1e3,
                                 min(adds), max(adds), now, None])
             del self.bursts[:-64]
+            srt = sorted(adds)                # the longest pause between two arrivals of the burst: what the window must outlast
+            gaps = sorted((b - a for a, b in zip(srt, srt[1:])), reverse=True) + [0.0, 0.0]
+            self.burst_gaps.append((len(adds), gaps[0] * 1e3, gaps[1] * 1e3))
+            del self.burst_gaps[:-64]
         return msgs
 
     def _exchange(self, msgs: list) -> list:
