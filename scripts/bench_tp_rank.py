@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--oneshot", action="store_true",
                     help="keep the all-reduce launches: a one-rank communicator of the one-shot kernel (slab sums formed "
                          "inside it) instead of no-ops")
+    ap.add_argument("--only", default=None,
+                    help="one variant instead of all six, e.g. sharded-timed, replicated-library (for a profiler run)")
     a = ap.parse_args()
     cfg = ModelConfig.from_pretrained(a.model)
     L = a.layers or cfg.num_hidden_layers
@@ -81,6 +83,9 @@ def main():
         batch = a.batch_per_gpu * tp
         for shard in (False, True):
             for tiled in (True, False, None):
+                name = f"{'sharded' if shard else 'replicated'}-{ {True: 'tiled', False: 'library', None: 'timed'}[tiled]}"
+                if a.only and a.only != name:
+                    continue
                 ms, used, tuned, plans = step_ms(cfg, tp, batch, a.ctx, shard, tiled, L, a.oneshot)
                 if tiled is True and used == "-----":
                     continue                              # no tiled kernels for this row count: same as library
