@@ -4,7 +4,10 @@
 // the outputs differ by one rounding step: another order of additions) and measured slower on every shape it was
 // built for: Qwen2-7B gate_up at 64 rows 36.8 us (fp8) / 55.0 (bf16) against 33.3 / 49.7 with two tiles per wave;
 // the slices of a Llama-3-8B TP4 / TP8 rank at 128 / 256 rows in row blocks of 64: never among the best four forms.
-// What it halves -- the LDS reads per weight byte -- is not what bounds those launches.
+// What it halves -- the LDS reads per weight byte -- is not what bounds those launches.  The same kernel with TWO
+// tiles per wave and the K range split across 4 waves (as many workgroups as the one-tile form 302, half its LDS
+// reads; TPW as a template parameter, tiles_per_wg 702 / 704 / 708 / 802 / 804) was measured too: gate_up of a TP4
+// rank at 128 rows, unsplit, 21.65 us against 20.47 for 302; down 15.4 (708) against 13.8 (304).
 // ---- FOUR tiles per wave, K split across the waves of a workgroup (33 .. 64 rows per row block).
 // From 64 rows on the kernels above are bound by the LDS, not by HBM: a CU's LDS hands out about one
 // 1 KB fragment of x per 16 cycles, the time ONE of its four SIMDs needs for the MFMA that consumes
