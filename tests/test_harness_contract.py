@@ -43,6 +43,19 @@ def test_reference_generated_args_parse(case, kind):
     assert ea.quantization == cfg["quantization"]
     assert ea.dtype == cfg["dtype"]
     assert ea.resolved_dtype() in ("bfloat16", "float16")
+    # which 16-bit type a request is served in, given the type the checkpoint is stored in
+    from mi355_decode.config import EngineArgs as EA, ModelConfig
+    rule = {("auto", "bfloat16"): "bfloat16", ("auto", "float16"): "float16", ("auto", "float32"): "float16",
+            ("auto", None): "bfloat16", ("float32", "float16"): "float16", ("float32", "bfloat16"): "bfloat16",
+            ("float32", "float32"): "bfloat16", ("float32", None): "bfloat16", ("half", "bfloat16"): "float16",
+            ("bfloat16", "float16"): "bfloat16", ("float16", None): "float16"}
+    for (asked, stored), served in rule.items():
+        assert EA(model="x", dtype=asked).resolved_dtype(stored) == served, (asked, stored)
+    assert ModelConfig.from_pretrained("facebook/opt-125m").torch_dtype == "float16"
+    assert ModelConfig.from_pretrained("llama-3-8b").torch_dtype == "bfloat16"
+    assert ModelConfig.from_dict({**{k: v for k, v in __import__("mi355_decode.config", fromlist=["KNOWN_MODELS"])
+                                     .KNOWN_MODELS["qwen2-7b"].items() if k != "torch_dtype"},
+                                  "torch_dtype": "torch.float32"}).torch_dtype == "float32"
     # the templates always force these; they are accepted and non-binding
     assert ea.extra["device"] == "cpu" and ea.extra["enforce-eager"] == "advisory"
     assert ea.enforce_eager is False

@@ -22,20 +22,20 @@ KNOWN_MODELS = {
     "llama-3-8b": dict(architectures=["LlamaForCausalLM"], vocab_size=128256, hidden_size=4096,
                        intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
                        num_key_value_heads=8, rope_theta=500000.0, rms_norm_eps=1e-5,
-                       max_position_embeddings=8192, tie_word_embeddings=False),
+                       max_position_embeddings=8192, tie_word_embeddings=False, torch_dtype="bfloat16"),
     "llama-3-70b": dict(architectures=["LlamaForCausalLM"], vocab_size=128256, hidden_size=8192,
                         intermediate_size=28672, num_hidden_layers=80, num_attention_heads=64,
                         num_key_value_heads=8, rope_theta=500000.0, rms_norm_eps=1e-5,
-                        max_position_embeddings=8192, tie_word_embeddings=False),
+                        max_position_embeddings=8192, tie_word_embeddings=False, torch_dtype="bfloat16"),
     # the model the harness launches when a request names none (benchmark-vllm/models.py:7)
     "opt-125m": dict(architectures=["OPTForCausalLM"], vocab_size=50272, hidden_size=768, ffn_dim=3072,
                      num_hidden_layers=12, num_attention_heads=12, max_position_embeddings=2048,
                      word_embed_proj_dim=768, do_layer_norm_before=True, activation_function="relu",
-                     bos_token_id=2, eos_token_id=2),
+                     bos_token_id=2, eos_token_id=2, torch_dtype="float16"),      # published in float16
     "qwen2-7b": dict(architectures=["Qwen2ForCausalLM"], vocab_size=152064, hidden_size=3584,
                      intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28,
                      num_key_value_heads=4, rope_theta=1000000.0, rms_norm_eps=1e-6,
-                     max_position_embeddings=32768, tie_word_embeddings=False),
+                     max_position_embeddings=32768, tie_word_embeddings=False, torch_dtype="bfloat16"),
 }
 
 
@@ -69,6 +69,8 @@ class ModelConfig:
     # bias, learned positions stored at an offset, biased projections, fc1 -> ReLU -> fc2)
     family: str = "llama"
     position_offset: int = 0
+    # the type the checkpoint's weights are stored in (config.json's torch_dtype / dtype), if it says
+    torch_dtype: Optional[str] = None
 
     @classmethod
     def _from_opt_dict(cls, d: dict) -> "ModelConfig":
@@ -98,8 +100,12 @@ class ModelConfig:
         arch = archs[0]
         if arch not in SUPPORTED_ARCHS:
             raise ValueError(f"architecture {arch!r} is not supported (supported: {SUPPORTED_ARCHS})")
+        stored = str(d.get("torch_dtype") or d.get("dtype") or "").replace("torch.", "").lower()
+        stored = _DTYPES.get(stored) if stored and stored != "auto" else None
         if arch == "OPTForCausalLM":
-            return cls._from_opt_dict(d)
+            cfg = cls._from_opt_dict(d)
+            cfg.torch_dtype = stored
+            return cfg
         nh = d["num_attention_heads"]
         rope_params = d.get("rope_parameters") or {}
         rope_scaling = d.get("rope_scaling")
@@ -129,6 +135,7 @@ class ModelConfig:
             attention_bias=bool(d.get("attention_bias", arch == "Qwen2ForCausalLM")),
             bos_token_id=d.get("bos_token_id"),
             eos_token_id=d.get("eos_token_id"),
+            torch_dtype=stored,
         )
 
     @classmethod
@@ -200,14 +207,23 @@ class EngineArgs:
     num_layers_override: Optional[int] = None      # testing / bounded benchmarks only
     extra: dict = field(default_factory=dict)      # accepted-and-ignored engine flags
 
-    def resolved_dtype(self) -> str:
-        """The 16-bit arithmetic type the kernels run in.  float32 requests are
-        served in bfloat16 (same exponent range); the kernels have no fp32 path."""
+    def resolved_dtype(self, checkpoint_dtype: Optional[str] = None) -> str:
+        """The 16-bit arithmetic type the kernels run in; `checkpoint_dtype`: the type the weights are
+        stored in (ModelConfig.torch_dtype), if known.  An explicit 16-bit --dtype is taken as is.
+        `auto` follows the rule of the engine this one replaces: a bfloat16 checkpoint is served in
+        bfloat16, a float16 or float32 one in float16.  `float32` (the harness's default,
+        benchmark-vllm/models.py:14) cannot be had -- the kernels have no fp32 path --: a 16-bit
+        checkpoint is then served in its own type (every stored weight exact; OPT is float16), a
+        float32 or unlabelled one in bfloat16 (same exponent range: nothing overflows)."""
         key = (self.dtype or "auto").lower()
         if key not in _DTYPES:
             raise ValueError(f"--dtype {self.dtype!r} not understood")
+        if key == "auto":
+            return {"bfloat16": "bfloat16", "float16": "float16", "float32": "float16"}.get(checkpoint_dtype, "bfloat16")
         dt = _DTYPES[key]
-        return "bfloat16" if dt == "float32" else dt
+        if dt == "float32":
+            return checkpoint_dtype if checkpoint_dtype in ("bfloat16", "float16") else "bfloat16"
+        return dt
 
     def validate(self) -> None:
         if self.pipeline_parallel_size != 1:

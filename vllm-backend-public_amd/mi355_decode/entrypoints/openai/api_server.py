@@ -477,7 +477,7 @@ def main(argv: Optional[List[str]] = None) -> int:
 
     import uvicorn
     app = build_app(thread, served, tokenizer, cfg.vocab_size, max_model_len,
-                    requested_dtype=(args.dtype or "auto"), served_dtype=args.resolved_dtype())
+                    requested_dtype=(args.dtype or "auto"), served_dtype=args.resolved_dtype(cfg.torch_dtype))
     thread.start()
     config = uvicorn.Config(app, host=ns.host, port=ns.port, log_level="warning", access_log=False)
     server = uvicorn.Server(config)

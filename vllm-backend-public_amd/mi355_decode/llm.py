@@ -79,9 +79,10 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
     args.validate()
     rank, world, device, group = init_distributed(args.tensor_parallel_size)
     cfg = model_config or ModelConfig.from_pretrained(args.model)
-    dtype = TORCH_DTYPE[args.resolved_dtype()]
+    dtype = TORCH_DTYPE[args.resolved_dtype(cfg.torch_dtype)]
     if (args.dtype or "").lower() in ("float32", "float"):
-        log.warning("--dtype float32 requested: the gfx950 kernels compute in 16 bits, serving in bfloat16")
+        log.warning("--dtype float32 requested: the gfx950 kernels compute in 16 bits, serving in %s (checkpoint "
+                    "stored in %s)", args.resolved_dtype(cfg.torch_dtype), cfg.torch_dtype or "an unlabelled type")
     if args.block_size != BLOCK_SIZE:
         log.warning("--block-size %d requested: this engine always uses %d-token KV pages",
                     args.block_size, BLOCK_SIZE)
