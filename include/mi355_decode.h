@@ -683,6 +683,14 @@ int32_t mi355_linear_tiled_w8a8(void* y, int64_t y_stride, void* partial, const 
  *            added in slab order and rounded once on the way into the peers' buffers -- what
  *            mi355_sum_slabs followed by run computes, without the launch in between.  `out`
  *            (count 16-bit elements) receives the sum over the ranks; on a timeout it is left as it was
+ *   run_add_norm  the all-reduce of an o_proj / down_proj result together with the kernel that
+ *            follows it in a decoder layer: the message is [rows][hidden] (data: this rank's 16-bit
+ *            partial rows, contiguous; or slabs as in run_slabs, data then null), a workgroup owns a
+ *            row, sums it over the ranks and goes on with residual = round(round(sum) + residual),
+ *            out = round(residual * inv_rms) * norm_weight -- bit-identical to run (or run_slabs)
+ *            followed by mi355_fused_add_rms_norm, one launch instead of two; the summed projection
+ *            itself is not stored.  rows <= 256, hidden <= 8192.  On a timeout residual and out are
+ *            left as they were
  *   status   synchronises with the queued work and returns MI355_ERR_LAUNCH if that happened
  *   status_async  queues a copy of the communicator's error word (0: every wait so far was met;
  *            1 + r: rank r once failed to arrive) to *host_word (pinned host memory) on the
@@ -700,6 +708,11 @@ int32_t mi355_allreduce_oneshot_run(void* comm, void* data, int64_t count,
 int32_t mi355_allreduce_oneshot_run_slabs(void* comm, void* out, const float* slabs,
                                           int32_t num_slabs, int64_t count, int32_t dtype,
                                           void* stream);
+int32_t mi355_allreduce_oneshot_run_add_norm(void* comm, const void* data, const float* slabs,
+                                             int32_t num_slabs, void* residual,
+                                             int64_t residual_stride, const void* norm_weight,
+                                             void* out, int64_t out_stride, int32_t rows,
+                                             int32_t hidden, float eps, int32_t dtype, void* stream);
 int32_t mi355_allreduce_oneshot_status(void* comm);
 int32_t mi355_allreduce_oneshot_status_async(void* comm, uint32_t* host_word, void* stream);
 int32_t mi355_allreduce_oneshot_destroy(void* comm);

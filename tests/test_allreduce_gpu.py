@@ -21,6 +21,7 @@ from oracle import ops_ref as R  # noqa: E402
 
 COUNTS = [8, 4096 * 16, 1000 * 8, 4096 * 128, 4096 * 256, 4096 * 32, 8, 4096 * 256]      # elements; 2 MiB = 4096 * 256 bf16
 SLAB_CASES = [(2, 4096 * 16), (8, 4096 * 128), (3, 1000 * 8), (4, 4096 * 256)]            # (slabs, elements)
+NORM_CASES = [(32, 4096, 0), (128, 4096, 4), (256, 4096, 0), (16, 8192, 2), (5, 3584, 0), (7, 1000, 1)]   # (rows, hidden, slabs)
 
 
 def _slabs(rank, i, n, count):
@@ -88,6 +89,48 @@ def _worker(rank, world, conns, dtype, out_q):
             T.cuda.synchronize()
             results.append(buf.float().cpu().numpy())
         ar.check()
+        # the all-reduce with the residual add + RMSNorm behind it in one launch: bit-identical to the all-reduce
+        # (from 16-bit rows or from slabs) followed by the add + norm kernel, eagerly and replayed from a graph
+        from mi355_decode import ops
+        for i, (rows, hidden, n) in enumerate(NORM_CASES):
+            count = rows * hidden
+            w = T.from_numpy(_inputs(0, 300 + i, hidden, dtype)).to(tdt).cuda()           # the same norm weight on every rank
+            resid0 = T.from_numpy(_inputs(0, 400 + i, count, dtype)).to(tdt).cuda().view(rows, hidden)
+            if n:
+                sl = T.from_numpy(_slabs(rank, 50 + i, n, count)).cuda()
+                ref = T.empty(rows, hidden, dtype=tdt, device="cuda")
+                ar.run_slabs(sl, n, ref.view(-1))
+            else:
+                mine = T.from_numpy(_inputs(rank, 500 + i, count, dtype)).to(tdt).cuda().view(rows, hidden)
+                ref = mine.clone()
+                ar.run(ref.view(-1))
+            resid_ref, x_ref = resid0.clone(), T.empty(rows, hidden, dtype=tdt, device="cuda")
+            ops.fused_add_rms_norm(ref, resid_ref, w, 1e-5, out=x_ref)
+            resid, x = resid0.clone(), T.full((rows, hidden), 7.0, dtype=tdt, device="cuda")
+            if n:
+                ar.run_add_norm(resid, w, 1e-5, x, slabs=sl, num_slabs=n)
+            else:
+                ar.run_add_norm(resid, w, 1e-5, x, data=mine)
+            T.cuda.synchronize()
+            assert T.equal(resid, resid_ref) and T.equal(x, x_ref), ("fused all-reduce + norm", rows, hidden, n)
+            results.append(x.float().cpu().numpy().ravel())          # every rank must hold the same rows
+        rows, hidden = 32, 4096
+        mine = T.zeros(rows, hidden, dtype=tdt, device="cuda")
+        resid, x = T.zeros(rows, hidden, dtype=tdt, device="cuda"), T.zeros(rows, hidden, dtype=tdt, device="cuda")
+        w = T.from_numpy(_inputs(0, 399, hidden, dtype)).to(tdt).cuda()
+        ar.run_add_norm(resid, w, 1e-5, x, data=mine)
+        T.cuda.synchronize()
+        g2 = T.cuda.CUDAGraph()
+        with T.cuda.graph(g2):
+            ar.run_add_norm(resid, w, 1e-5, x, data=mine)
+        for k in range(2):
+            mine.copy_(T.from_numpy(_inputs(rank, 600 + k, rows * hidden, dtype)).to(tdt).view(rows, hidden))
+            resid.copy_(T.from_numpy(_inputs(0, 700 + k, rows * hidden, dtype)).to(tdt).view(rows, hidden))
+            g2.replay()
+            T.cuda.synchronize()
+            results.append(x.float().cpu().numpy().ravel())
+            results.append(resid.float().cpu().numpy().ravel())
+        ar.check()
         ar.close()
         out_q.put((rank, "ok", results))
     except Exception as exc:                                      # noqa: BLE001
@@ -125,10 +168,23 @@ def test_ranks_on_one_gpu_match_the_host_sum(dtype, world):
     wants = [rank_sum([_inputs(r, i, c, dtype) for r in range(world)]) for i, c in enumerate(COUNTS)]
     wants += [rank_sum([_slab_sum(_slabs(r, i, n + 1, c)[:n], dtype) for r in range(world)]) for i, (n, c) in enumerate(SLAB_CASES)]
     wants += [rank_sum([_inputs(r, 100 + k, 4096 * 32, dtype) for r in range(world)]) for k in range(3)]
-    assert all(len(got[r]) == len(wants) for r in range(world))
+    extra = len(NORM_CASES) + 4                                  # the fused all-reduce + norm results: checked against the
+    assert all(len(got[r]) == len(wants) + extra for r in range(world))   # unfused pair inside the workers; here: equal on every rank
     for j, want in enumerate(wants):
         for r in range(world):
             np.testing.assert_array_equal(got[r][j], want, err_msg=f"rank {r}, call {j} ({want.size} elements)")
+    for j in range(len(wants), len(wants) + extra):
+        for r in range(1, world):
+            np.testing.assert_array_equal(got[r][j], got[0][j], err_msg=f"rank {r}, fused call {j}")
+    # the graph replays against the oracle: all-reduce in rank order, then the add + norm
+    for k in range(2):
+        summed = rank_sum([_inputs(r, 600 + k, 32 * 4096, dtype) for r in range(world)]).reshape(32, 4096)
+        x_want, resid_want = R.fused_add_rms_norm(summed, _inputs(0, 700 + k, 32 * 4096, dtype).reshape(32, 4096),
+                                                  _inputs(0, 399, 4096, dtype), 1e-5, dtype)
+        j = len(wants) + len(NORM_CASES) + 2 * k
+        np.testing.assert_array_equal(got[0][j + 1].reshape(32, 4096), resid_want)      # the residual add is exact
+        bad = got[0][j].reshape(32, 4096) != x_want
+        assert bad.mean() <= 0.005, bad.mean()                                          # the norm's bar of the ops tests
 
 
 def test_single_rank_is_the_identity_and_sizes_are_checked():
@@ -146,6 +202,17 @@ def test_single_rank_is_the_identity_and_sizes_are_checked():
     assert torch.equal(out, ((slabs[0] + slabs[1]) + slabs[2]).to(torch.bfloat16))
     with pytest.raises(Mi355Error, match="num_slabs"):
         ar.run_slabs(torch.randn(9, 4096, device="cuda"), 9, out)
+    from mi355_decode import ops
+    w = torch.randn(4096, device="cuda").to(torch.bfloat16)
+    part, resid = torch.randn(8, 4096, device="cuda").to(torch.bfloat16), torch.randn(8, 4096, device="cuda").to(torch.bfloat16)
+    resid_ref, x_ref = resid.clone(), torch.empty_like(resid)
+    ops.fused_add_rms_norm(part.clone(), resid_ref, w, 1e-5, out=x_ref)
+    x = torch.empty_like(resid)
+    ar.run_add_norm(resid, w, 1e-5, x, data=part)                 # one rank: the add + norm of its own rows
+    assert torch.equal(resid, resid_ref) and torch.equal(x, x_ref)
+    with pytest.raises(ValueError):
+        ar.run_add_norm(resid, w, 1e-5, x)                        # neither data nor slabs
+    assert not ar.fits_add_norm(257, 64, torch.bfloat16) and not ar.fits_add_norm(8, 8200, torch.bfloat16)
     assert ar.self_test("cuda")
     assert not ar.fits(torch.zeros((1 << 15) + 8, dtype=torch.bfloat16, device="cuda"))   # beyond max_bytes
     assert not ar.fits(torch.zeros(12, dtype=torch.bfloat16, device="cuda"))               # not a multiple of 8

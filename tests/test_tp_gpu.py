@@ -66,12 +66,16 @@ def _worker(rank, world, port, name, dtype, shard_mlp, q, oneshot=False):
         toks = engine_generate(eng, make_prompts(name, len(LENGTHS), LENGTHS), GEN)
         steps = eng.stats["decode_steps"] + eng.stats["prefill_steps"]
         per_step = r.L * (2 if shard_mlp else 1)               # a step launched ahead may not be counted yet
-        assert calls[0] % per_step == 0 and calls[0] >= steps * per_step, (calls[0], steps)
+        # with the one-shot kernel a decode step's all-reduces run together with the add + norm behind them
+        # (one launch, past the two wrappers counted above)
+        total = calls[0] + r.fused_allreduce_norms
+        assert total % per_step == 0 and total >= steps * per_step, (calls[0], r.fused_allreduce_norms, steps)
         if oneshot:                                             # every message of these tiny models fits the one-shot kernel
-            assert r.oneshot is not None and r.oneshot_calls == calls[0], (r.oneshot_calls, calls[0])
+            assert r.oneshot is not None and r.oneshot_calls == total, (r.oneshot_calls, total)
+            assert r.fused_allreduce_norms >= eng.stats["decode_steps"] * per_step > 0
             r.oneshot.check()
         else:
-            assert r.oneshot is None
+            assert r.oneshot is None and r.fused_allreduce_norms == 0
         # random sampling and log-probabilities need whole rows: gathered from the ranks' slices
         from mi355_decode.sampling_params import SamplingParams
         sampled = {}

@@ -82,21 +82,37 @@ __device__ __forceinline__ void ar_wait_loads(ar_u32x4& r) {       // ties the v
 
 constexpr int kArVecPerThread = 2;   // 16-byte vectors a thread holds in flight per pass
 
+// The residual add + RMSNorm that follows the all-reduce of an o_proj / down_proj result, done by the
+// workgroups that have just summed it (NV > 0: a workgroup owns ONE row of the [rows][hidden] message,
+// a thread NV 16-byte vectors of it): residual = round(round(sum) + residual), out = round(residual *
+// inv_rms) * weight -- the arithmetic, the thread-to-vector map and the order of the sum of squares of
+// rms_norm_slabs_kernel, so the fused call is bit-identical to the all-reduce followed by
+// mi355_fused_add_rms_norm; the summed projection itself is not written anywhere (nobody reads it).
+struct ArNorm {
+  uint16_t* residual;       // [rows][res_stride] in/out
+  const uint16_t* weight;   // [hidden]
+  uint16_t* out;            // [rows][out_stride]
+  int64_t res_stride, out_stride;
+  int hidden;
+  float eps;
+};
+
 // `slabs` != nullptr: this rank's input is not `data` but round(slabs[0] + slabs[1] + ...), fp32
 // partial sums [num_slabs][count] of a projection whose K was split over workgroups, added in slab
 // order and rounded once -- the 16-bit tensor a separate slab-summing launch would have formed
 // (mi355_sum_slabs), formed here on the way into the peers' buffers; `data` is then output only.
-template <typename T>
+template <typename T, int NV = 0>
 __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
     uint16_t* __restrict__ data, int64_t count, ArPeers peers, int rank, int world, int64_t max_bytes,
-    unsigned* __restrict__ rounds, unsigned* __restrict__ error, const float* __restrict__ slabs, int num_slabs) {
+    unsigned* __restrict__ rounds, unsigned* __restrict__ error, const float* __restrict__ slabs, int num_slabs,
+    ArNorm nm) {
   const int b = blockIdx.x, nb = gridDim.x, tid = threadIdx.x;
   // the call's round: one more than the last completed call's (nobody advances the word before
   // every workgroup of this call has finished, hence read it)
   const unsigned round = __hip_atomic_load(rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
   const int parity = round & 1;
   const int64_t nvec = count >> 3;                    // 16-byte vectors (count % 8 == 0)
-  const int64_t per = (nvec + nb - 1) / nb;
+  const int64_t per = NV > 0 ? (nm.hidden >> 3) : (nvec + nb - 1) / nb;   // NV > 0: chunk b is row b
   const int64_t v0 = b * per, v1 = min(nvec, v0 + per);
   const int64_t slot_bytes = max_bytes;
   const int64_t flags_off = ar_flags_offset(world, max_bytes);
@@ -119,6 +135,18 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
       mine_v = src[v];
     }
     for (int p = 0; p < world; ++p) ar_store_sys(peers.buf[p] + slot_off + v * 16, mine_v);
+  }
+  // the norm's own operands are asked for here: they arrive while the flags are waited for
+  uint4 nres[NV > 0 ? NV : 1], nw[NV > 0 ? NV : 1];
+  if (NV > 0) {
+    const uint4* rr = reinterpret_cast<const uint4*>(nm.residual + static_cast<int64_t>(b) * nm.res_stride);
+    const uint4* wv = reinterpret_cast<const uint4*>(nm.weight);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = min(tid + i * kArThreads, static_cast<int>(per) - 1);
+      nres[i] = MI355_LD(uint4, nm.residual, rr + v);
+      nw[i] = MI355_LD(uint4, nm.weight, wv + v);
+    }
   }
   // 2. stores first, then the flag: every storing wave waits until its stores have been acknowledged,
   //    the workgroup meets, then one lane per peer raises this chunk's flag there
@@ -151,7 +179,70 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
   }
   __syncthreads();                                    // the data loads below come after every flag was seen
   const bool ok_all = ok_s != 0;
-  if (ok_all) {
+  if (NV > 0) {
+    // 4'. the row's sum (rank order, fp32, one rounding -- as below), then the residual add and the norm
+    __shared__ float part[kArThreads / 64];
+    float f[NV > 0 ? NV : 1][8];
+    float ss = 0.f;
+    if (ok_all) {
+      const unsigned char* mine = peers.buf[rank] + static_cast<int64_t>(parity) * world * slot_bytes;
+      ar_u32x4 in[NV > 0 ? NV : 1][kArMaxWorld];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int64_t v = v0 + min(tid + i * kArThreads, static_cast<int>(per) - 1);
+#pragma unroll
+        for (int p = 0; p < kArMaxWorld; ++p)
+          if (p < world) in[i][p] = ar_load_sys(mine + p * slot_bytes + v * 16);
+      }
+      uint4* rr = reinterpret_cast<uint4*>(nm.residual + static_cast<int64_t>(b) * nm.res_stride);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * kArThreads;
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int p = 0; p < kArMaxWorld; ++p) {
+          if (p < world) {
+            ar_wait_loads(in[i][p]);
+            float g[8];
+            unpack8<T>(make_uint4(in[i][p].x, in[i][p].y, in[i][p].z, in[i][p].w), g);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] += g[q];
+          }
+        }
+        float r[8];
+        unpack8<T>(pack8<T>(acc), f[i]);               // the 16-bit tensor the plain all-reduce would have left
+        unpack8<T>(nres[i], r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[i][j] = round_f<T>(f[i][j] + r[j]);
+        if (v < per) {
+          MI355_ST(uint4, nm.residual, rr + v, pack8<T>(f[i]));
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ss += f[i][j] * f[i][j];
+        }
+      }
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) part[tid >> 6] = ss;
+    __syncthreads();
+    if (ok_all) {
+      float total = 0.f;
+#pragma unroll
+      for (int i = 0; i < kArThreads / 64; ++i) total += part[i];
+      const float inv = 1.0f / sqrtf(total / static_cast<float>(nm.hidden) + nm.eps);
+      uint4* orow = reinterpret_cast<uint4*>(nm.out + static_cast<int64_t>(b) * nm.out_stride);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * kArThreads;
+        float w[8], y[8];
+        unpack8<T>(nw[i], w);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = round_f<T>(f[i][j] * inv) * w[j];
+        if (v < per) MI355_ST(uint4, nm.out, orow + v, pack8<T>(y));
+      }
+    }
+  } else if (ok_all) {
     // 4. sum in rank order, fp32, one rounding; the loads of a pass (vectors x ranks) are all in flight together
     const unsigned char* mine = peers.buf[rank] + static_cast<int64_t>(parity) * world * slot_bytes;
     uint4* out = reinterpret_cast<uint4*>(data);
@@ -251,14 +342,15 @@ extern "C" int32_t mi355_allreduce_oneshot_connect(void* comm, const void* all_h
 }
 
 static int32_t allreduce_oneshot_launch(const char* name, void* comm, void* data, const float* slabs, int32_t num_slabs,
-                                        int64_t count, int32_t dtype, void* stream) {
+                                        int64_t count, int32_t dtype, void* stream, const mi355::ArNorm* norm = nullptr,
+                                        int32_t rows = 0) {
   using namespace mi355;
-  MI355_REQUIRE(comm && data, MI355_ERR_INVALID, "%s: null pointer", name);
+  MI355_REQUIRE(comm && (data || (norm && slabs)), MI355_ERR_INVALID, "%s: null pointer", name);
   ArComm* c = static_cast<ArComm*>(comm);
   MI355_REQUIRE(c->connected, MI355_ERR_INVALID, "%s: not connected (exchange the handles first)", name);
   MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED, "%s: dtype %d not supported (bf16/fp16 only)",
                 name, dtype);
-  MI355_REQUIRE(count >= 0 && count % 8 == 0 && count * 2 <= c->max_bytes && aligned16(data), MI355_ERR_INVALID,
+  MI355_REQUIRE(count >= 0 && count % 8 == 0 && count * 2 <= c->max_bytes && (data == nullptr || aligned16(data)), MI355_ERR_INVALID,
                 "%s: count %lld must be a multiple of 8 with count * 2 <= max_bytes %lld, data 16-byte aligned", name,
                 (long long)count, (long long)c->max_bytes);
   MI355_REQUIRE(slabs == nullptr || (num_slabs >= 1 && num_slabs <= 8 && aligned16(slabs)), MI355_ERR_INVALID,
@@ -271,12 +363,22 @@ static int32_t allreduce_oneshot_launch(const char* name, void* comm, void* data
   int nb = static_cast<int>((count * 2 + 8191) / 8192);
   nb = nb < 1 ? 1 : nb > kArMaxBlocks ? kArMaxBlocks : nb;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dtype == MI355_BF16)
-    hipLaunchKernelGGL((allreduce_oneshot_kernel<BF16>), dim3(nb), dim3(kArThreads), 0, s, static_cast<uint16_t*>(data),
-                       count, peers, c->rank, c->world, c->max_bytes, c->rounds, c->error, slabs, num_slabs);
-  else
-    hipLaunchKernelGGL((allreduce_oneshot_kernel<F16>), dim3(nb), dim3(kArThreads), 0, s, static_cast<uint16_t*>(data),
-                       count, peers, c->rank, c->world, c->max_bytes, c->rounds, c->error, slabs, num_slabs);
+#define MI355_AR_LAUNCH(T_, NV_, NB_, NM_)                                                                               \
+  hipLaunchKernelGGL((allreduce_oneshot_kernel<T_, NV_>), dim3(NB_), dim3(kArThreads), 0, s, static_cast<uint16_t*>(data), \
+                     count, peers, c->rank, c->world, c->max_bytes, c->rounds, c->error, slabs, num_slabs, NM_)
+  if (norm != nullptr) {             // one workgroup per row (the same count on every rank: it is the row count)
+    const bool wide = (norm->hidden >> 3) > 2 * kArThreads;
+    if (dtype == MI355_BF16) {
+      if (wide) MI355_AR_LAUNCH(BF16, 4, rows, *norm); else MI355_AR_LAUNCH(BF16, 2, rows, *norm);
+    } else {
+      if (wide) MI355_AR_LAUNCH(F16, 4, rows, *norm); else MI355_AR_LAUNCH(F16, 2, rows, *norm);
+    }
+  } else if (dtype == MI355_BF16) {
+    MI355_AR_LAUNCH(BF16, 0, nb, ArNorm{});
+  } else {
+    MI355_AR_LAUNCH(F16, 0, nb, ArNorm{});
+  }
+#undef MI355_AR_LAUNCH
   return check_launch(name);
 }
 
@@ -290,6 +392,28 @@ extern "C" int32_t mi355_allreduce_oneshot_run_slabs(void* comm, void* out, cons
   const char* name = "mi355_allreduce_oneshot_run_slabs";
   MI355_REQUIRE(slabs != nullptr, MI355_ERR_INVALID, "%s: null pointer", name);
   return allreduce_oneshot_launch(name, comm, out, slabs, num_slabs, count, dtype, stream);
+}
+
+extern "C" int32_t mi355_allreduce_oneshot_run_add_norm(void* comm, const void* data, const float* slabs, int32_t num_slabs,
+                                                        void* residual, int64_t residual_stride, const void* norm_weight,
+                                                        void* out, int64_t out_stride, int32_t rows, int32_t hidden,
+                                                        float eps, int32_t dtype, void* stream) {
+  using namespace mi355;
+  const char* name = "mi355_allreduce_oneshot_run_add_norm";
+  MI355_REQUIRE(residual && norm_weight && out && (data || slabs), MI355_ERR_INVALID, "%s: null pointer", name);
+  MI355_REQUIRE(rows >= 0 && rows <= kArMaxBlocks, MI355_ERR_UNSUPPORTED, "%s: rows %d outside [0, %d]", name, rows,
+                kArMaxBlocks);
+  MI355_REQUIRE(hidden > 0 && hidden % 8 == 0 && (hidden >> 3) <= 4 * kArThreads, MI355_ERR_UNSUPPORTED,
+                "%s: hidden %d must be a multiple of 8, at most %d", name, hidden, 32 * kArThreads);
+  MI355_REQUIRE(residual_stride >= hidden && residual_stride % 8 == 0 && out_stride >= hidden && out_stride % 8 == 0 &&
+                    aligned16(residual) && aligned16(norm_weight) && aligned16(out) && eps >= 0.f,
+                MI355_ERR_INVALID, "%s: residual / norm_weight / out must be 16-byte aligned, strides >= hidden and multiples of 8",
+                name);
+  if (rows == 0) return MI355_OK;
+  const ArNorm nm{static_cast<uint16_t*>(residual), static_cast<const uint16_t*>(norm_weight), static_cast<uint16_t*>(out),
+                  residual_stride, out_stride, hidden, eps};
+  return allreduce_oneshot_launch(name, comm, const_cast<void*>(data), slabs, slabs ? num_slabs : 0,
+                                  static_cast<int64_t>(rows) * hidden, dtype, stream, &nm, rows);
 }
 
 extern "C" int32_t mi355_allreduce_oneshot_status_async(void* comm, uint32_t* host_word, void* stream) {

@@ -82,6 +82,40 @@ class OneShotAllReduce:
                                                     _DT[out.dtype], _stream()))
         return out
 
+    MAX_NORM_ROWS, MAX_NORM_HIDDEN = 256, 8192
+
+    def fits_add_norm(self, rows: int, hidden: int, dtype) -> bool:
+        return (dtype in (torch.bfloat16, torch.float16) and 0 < rows <= self.MAX_NORM_ROWS and hidden % 8 == 0
+                and hidden <= self.MAX_NORM_HIDDEN and rows * hidden * 2 <= self.max_bytes)
+
+    def run_add_norm(self, residual: torch.Tensor, weight: torch.Tensor, eps: float, out: torch.Tensor,
+                     data: torch.Tensor | None = None, slabs: torch.Tensor | None = None, num_slabs: int = 0) -> torch.Tensor:
+        """The all-reduce of a projection's [rows, hidden] result and the residual add + RMSNorm behind it in one
+        launch: residual += sum over the ranks (of `data`, or of the rounded slab sum), out = norm(residual) * weight;
+        bit-identical to run / run_slabs followed by ops.fused_add_rms_norm.  The reduced projection is not stored."""
+        rows, hidden = residual.shape
+        if not self.fits_add_norm(rows, hidden, residual.dtype):
+            raise ValueError(f"one-shot all-reduce + norm takes up to {self.MAX_NORM_ROWS} rows of up to "
+                             f"{self.MAX_NORM_HIDDEN} 16-bit elements within {self.max_bytes} bytes")
+        if (data is None) == (slabs is None):
+            raise ValueError("exactly one of data / slabs")
+        for t, n in ((residual, "residual"), (out, "out")):
+            if not t.is_cuda or t.dtype != residual.dtype or tuple(t.shape) != (rows, hidden) or t.stride(1) != 1:
+                raise ValueError(f"{n} must be a [rows, hidden] GPU tensor of the message's dtype with unit column stride")
+        if weight.dtype != residual.dtype or weight.numel() != hidden or not weight.is_contiguous() or not weight.is_cuda:
+            raise ValueError("weight must be contiguous [hidden] in the message's dtype")
+        if data is not None and (not data.is_cuda or data.dtype != residual.dtype or not data.is_contiguous()
+                                 or data.numel() != rows * hidden):
+            raise ValueError("data must be a contiguous [rows, hidden] GPU tensor of the message's dtype")
+        if slabs is not None and (slabs.dtype != torch.float32 or not slabs.is_cuda or not slabs.is_contiguous()
+                                  or num_slabs < 1 or slabs.numel() < num_slabs * rows * hidden):
+            raise ValueError("slabs must be contiguous float32 holding [num_slabs, rows * hidden]")
+        check(lib.mi355_allreduce_oneshot_run_add_norm(
+            self._comm, data.data_ptr() if data is not None else 0, slabs.data_ptr() if slabs is not None else 0,
+            num_slabs, residual.data_ptr(), residual.stride(0), weight.data_ptr(), out.data_ptr(), out.stride(0),
+            rows, hidden, float(eps), _DT[residual.dtype], _stream()))
+        return out
+
     def check(self) -> None:
         """Synchronises with the queued work; raises if a wait of any call so far timed out."""
         check(lib.mi355_allreduce_oneshot_status(self._comm))

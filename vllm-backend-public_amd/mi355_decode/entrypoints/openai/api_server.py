@@ -165,7 +165,8 @@ def build_app(engine_thread, served_model_name: str, tokenizer, vocab_size: int,
                           f"mi355_gemm_tune_failures_total {r.tune_failures}"]
                 if getattr(r, "tp_size", 1) > 1:               # which all-reduce serves the decode-sized messages
                     lines += [f"mi355_oneshot_allreduce_enabled {int(getattr(r, 'oneshot', None) is not None)}",
-                              f"mi355_oneshot_allreduce_fallbacks_total {getattr(r, 'oneshot_fallbacks', 0)}"]
+                              f"mi355_oneshot_allreduce_fallbacks_total {getattr(r, 'oneshot_fallbacks', 0)}",
+                              f"mi355_allreduce_norm_fused_total {getattr(r, 'fused_allreduce_norms', 0)}"]
                 for bucket, mode in sorted(getattr(r, "_modes", {}).items()):
                     for proj, tiled in mode.items():
                         lines.append(f'mi355_gemm_form{{bucket="{bucket}",projection="{proj}"}} {int(bool(tiled))}')

@@ -16,6 +16,7 @@ prefill runs eagerly.
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 from typing import Optional
@@ -106,6 +107,7 @@ class ModelRunner:
         self._device_collectives = None               # decided at the first collective (see _collective)
         self.oneshot = None                           # collectives.OneShotAllReduce, set by build_engine (opt-in)
         self.oneshot_calls = 0
+        self.fused_allreduce_norms = 0                # ... of which all-reduce + residual add + norm in one launch
         self.oneshot_fallbacks = 0                    # set-ups that ended on the process group's all-reduce instead
         self._no_collectives = False                  # True while GEMM forms are timed (tune)
         self.decode_splits = decode_splits
@@ -568,14 +570,25 @@ class ModelRunner:
                 self._linear_tiled(attn, tw["o"], self.H, partial=self.part_o, tiles_per_wg=t_, k_groups=g_, epilogue=P)
                 ops.fused_add_rms_norm_partial(self.part_o, g_, resid, lw.post_norm, self.eps, x)
                 return
+            fused = self._allreduce_norm_fused(b)         # the all-reduce, the residual add and the norm in one launch
             if tiled and g_ > 1:
                 self._linear_tiled(attn, tw["o"], self.H, partial=self.part_o, tiles_per_wg=t_, k_groups=g_, epilogue=P)
+                if fused:
+                    self.oneshot.run_add_norm(resid, lw.post_norm, self.eps, x, slabs=self.part_o, num_slabs=g_)
+                    self.oneshot_calls += 1
+                    self.fused_allreduce_norms += 1
+                    return
                 self._allreduce_slabs(self.part_o, g_, o)
             else:
                 if tiled:
                     self._linear_tiled(attn, tw["o"], self.H, out=o, tiles_per_wg=t_)
                 else:
                     torch.mm(attn, self._rm(i, "o").t(), out=o)
+                if fused:
+                    self.oneshot.run_add_norm(resid, lw.post_norm, self.eps, x, data=o)
+                    self.oneshot_calls += 1
+                    self.fused_allreduce_norms += 1
+                    return
                 self._allreduce(o)
             ops.fused_add_rms_norm(o, resid, lw.post_norm, self.eps, out=x)
         elif kind == "gu":
@@ -593,15 +606,17 @@ class ModelRunner:
             if tiled and not self.mlp_sharded:            # slabs for the add + norm kernel that follows (_add_mlp_and_norm)
                 self._linear_tiled(act, tw["down"], self.H, partial=self.part_dn, tiles_per_wg=t_, k_groups=g_, epilogue=P)
                 return
+            fused = self.mlp_sharded and self._allreduce_norm_fused(b)    # then _add_mlp_and_norm reduces what is left here
             if tiled and g_ > 1:
                 self._linear_tiled(act, tw["down"], self.H, partial=self.part_dn, tiles_per_wg=t_, k_groups=g_, epilogue=P)
-                self._allreduce_slabs(self.part_dn, g_, dn)
+                if not fused:
+                    self._allreduce_slabs(self.part_dn, g_, dn)
             else:
                 if tiled:
                     self._linear_tiled(act, tw["down"], self.H, out=dn, tiles_per_wg=t_)
                 else:
                     torch.mm(act, self._rm(i, "down").t(), out=dn)
-                if self.mlp_sharded:
+                if self.mlp_sharded and not fused:
                     self._allreduce(dn)
         else:
             raise ValueError(kind)
@@ -611,9 +626,18 @@ class ModelRunner:
         when it left slabs (tiled, MLP not sharded), from its 16-bit result otherwise."""
         if tiled is None:
             tiled = self._mode(b)["down"]
+        g_ = (plan or self._tiled_plan(self.bucket_for(b))["down"])[1] if tiled else 1
         if tiled and not self.mlp_sharded:
-            g_ = (plan or self._tiled_plan(self.bucket_for(b))["down"])[1]
             ops.fused_add_rms_norm_partial(self.part_dn, g_, self.resid[:b], weight, self.eps, self.x[:b])
+        elif self.mlp_sharded and self._allreduce_norm_fused(b):
+            # the down projection left this rank's partial result (16-bit rows, or slabs when its K was split):
+            # summed over the ranks, added to the residual and normed by one launch
+            if g_ > 1:
+                self.oneshot.run_add_norm(self.resid[:b], weight, self.eps, self.x[:b], slabs=self.part_dn, num_slabs=g_)
+            else:
+                self.oneshot.run_add_norm(self.resid[:b], weight, self.eps, self.x[:b], data=self.dn[:b])
+            self.oneshot_calls += 1
+            self.fused_allreduce_norms += 1
         else:
             ops.fused_add_rms_norm(self.dn[:b], self.resid[:b], weight, self.eps, out=self.x[:b])
 
@@ -718,6 +742,13 @@ class ModelRunner:
         want = max(1, 256 // max(wgs, 1))
         by_len = max(1, self.max_model_len // 256)      # keep >= 2 wave-steps per workgroup
         return max(1, min(want, by_len, self._max_splits))
+
+    def _allreduce_norm_fused(self, b: int) -> bool:
+        """True if the all-reduce behind o_proj / down_proj of a b-row decode step runs together with the residual
+        add + norm that follows it (the one-shot kernel's add + norm form: one launch instead of two)."""
+        return (self.tp_size > 1 and self.oneshot is not None and not self._no_collectives
+                and os.environ.get("MI355_ALLREDUCE_NORM", "1") != "0"
+                and self.oneshot.fits_add_norm(b, self.H, self.dtype))
 
     def _allreduce(self, t: torch.Tensor) -> None:
         """Sum of the ranks' partial results, in place.  Decode-sized 16-bit messages take the one-shot
