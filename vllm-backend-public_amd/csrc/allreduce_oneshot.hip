@@ -118,8 +118,12 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
   const int64_t flags_off = ar_flags_offset(world, max_bytes);
   const uint4* src = reinterpret_cast<const uint4*>(data);
 
-  // 1. deliver this rank's chunk to every rank (own buffer included: the sum below reads all slots alike)
+  // 1. deliver this rank's chunk to every rank (own buffer included: the sum below reads all slots alike;
+  //    NV > 0: the own chunk stays in registers instead -- no store to, flag in or load from the own buffer)
   const int64_t slot_off = (static_cast<int64_t>(parity) * world + rank) * slot_bytes;
+  uint4 own[NV > 0 ? NV : 1];
+#pragma unroll
+  for (int i = 0; i < (NV > 0 ? NV : 1); ++i) own[i] = make_uint4(0, 0, 0, 0);
   for (int64_t v = v0 + tid; v < v1; v += kArThreads) {
     uint4 mine_v;
     if (slabs != nullptr) {
@@ -134,7 +138,13 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
     } else {
       mine_v = src[v];
     }
-    for (int p = 0; p < world; ++p) ar_store_sys(peers.buf[p] + slot_off + v * 16, mine_v);
+    if (NV > 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (v == v0 + tid + i * kArThreads) own[i] = mine_v;
+    }
+    for (int p = 0; p < world; ++p)
+      if (NV == 0 || p != rank) ar_store_sys(peers.buf[p] + slot_off + v * 16, mine_v);
   }
   // the norm's own operands are asked for here: they arrive while the flags are waited for
   uint4 nres[NV > 0 ? NV : 1], nw[NV > 0 ? NV : 1];
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
   //    the workgroup meets, then one lane per peer raises this chunk's flag there
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid < world) {
+  if (tid < world && (NV == 0 || tid != rank)) {
     unsigned* flag = reinterpret_cast<unsigned*>(peers.buf[tid] + flags_off) + rank * kArMaxBlocks + b;
     __hip_atomic_store(flag, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
   __shared__ int ok_s;
   if (tid == 0) ok_s = 1;
   __syncthreads();
-  if (tid < world) {
+  if (tid < world && (NV == 0 || tid != rank)) {
     const unsigned* flag = reinterpret_cast<const unsigned*>(peers.buf[rank] + flags_off) + tid * kArMaxBlocks + b;
     const long long t0 = wall_clock64();
     bool ok = true;
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
         const int64_t v = v0 + min(tid + i * kArThreads, static_cast<int>(per) - 1);
 #pragma unroll
         for (int p = 0; p < kArMaxWorld; ++p)
-          if (p < world) in[i][p] = ar_load_sys(mine + p * slot_bytes + v * 16);
+          if (p < world && p != rank) in[i][p] = ar_load_sys(mine + p * slot_bytes + v * 16);
       }
       uint4* rr = reinterpret_cast<uint4*>(nm.residual + static_cast<int64_t>(b) * nm.res_stride);
 #pragma unroll
@@ -204,9 +214,13 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
 #pragma unroll
         for (int p = 0; p < kArMaxWorld; ++p) {
           if (p < world) {
-            ar_wait_loads(in[i][p]);
             float g[8];
-            unpack8<T>(make_uint4(in[i][p].x, in[i][p].y, in[i][p].z, in[i][p].w), g);
+            if (p == rank) {
+              unpack8<T>(own[i], g);                   // (a thread beyond the row holds nothing: its values go nowhere)
+            } else {
+              ar_wait_loads(in[i][p]);
+              unpack8<T>(make_uint4(in[i][p].x, in[i][p].y, in[i][p].z, in[i][p].w), g);
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc[q] += g[q];
           }
