@@ -691,6 +691,11 @@ int32_t mi355_linear_tiled_w8a8(void* y, int64_t y_stride, void* partial, const 
  *            followed by mi355_fused_add_rms_norm, one launch instead of two; the summed projection
  *            itself is not stored.  rows <= 256, hidden <= 8192.  On a timeout residual and out are
  *            left as they were
+ *   run_max_keys  the greedy pick of a step whose vocabulary is split over the ranks: keys[rows] are the
+ *            (logit, index) keys of this rank's slice (mi355_argmax_shard_key); they are max-reduced
+ *            over the ranks (signed 64-bit) and the winners' token ids written to out_ids (and to
+ *            out_ids2 unless null) -- the process group's MAX all-reduce and mi355_argmax_key_to_index
+ *            in one single-workgroup launch.  rows <= 256
  *   status   synchronises with the queued work and returns MI355_ERR_LAUNCH if that happened
  *   status_async  queues a copy of the communicator's error word (0: every wait so far was met;
  *            1 + r: rank r once failed to arrive) to *host_word (pinned host memory) on the
@@ -713,6 +718,8 @@ int32_t mi355_allreduce_oneshot_run_add_norm(void* comm, const void* data, const
                                              int64_t residual_stride, const void* norm_weight,
                                              void* out, int64_t out_stride, int32_t rows,
                                              int32_t hidden, float eps, int32_t dtype, void* stream);
+int32_t mi355_allreduce_oneshot_run_max_keys(void* comm, const int64_t* keys, int64_t* out_ids,
+                                             int64_t* out_ids2, int32_t rows, void* stream);
 int32_t mi355_allreduce_oneshot_status(void* comm);
 int32_t mi355_allreduce_oneshot_status_async(void* comm, uint32_t* host_word, void* stream);
 int32_t mi355_allreduce_oneshot_destroy(void* comm);

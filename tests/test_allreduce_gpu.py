@@ -130,6 +130,16 @@ def _worker(rank, world, conns, dtype, out_q):
             T.cuda.synchronize()
             results.append(x.float().cpu().numpy().ravel())
             results.append(resid.float().cpu().numpy().ravel())
+        # the greedy pick over a vocabulary split across the ranks: keys max-reduced and turned into ids in one launch
+        rows, vl = 37, 1000
+        lg = T.from_numpy(_inputs(rank, 800, rows * vl, dtype)).to(tdt).cuda().view(rows, vl)
+        lg[3] = 0.5                                               # a row tied across all ranks: the lowest index wins
+        keys = ops.argmax_shard_key(lg, rank * vl)
+        ids, ids2 = T.full((rows,), -1, dtype=T.int64, device="cuda"), T.full((rows,), -1, dtype=T.int64, device="cuda")
+        ar.run_max_keys(keys, ids, ids2)
+        T.cuda.synchronize()
+        assert T.equal(ids, ids2)
+        results.append(ids.cpu().numpy().astype(np.float32))
         ar.check()
         ar.close()
         out_q.put((rank, "ok", results))
@@ -168,7 +178,7 @@ def test_ranks_on_one_gpu_match_the_host_sum(dtype, world):
     wants = [rank_sum([_inputs(r, i, c, dtype) for r in range(world)]) for i, c in enumerate(COUNTS)]
     wants += [rank_sum([_slab_sum(_slabs(r, i, n + 1, c)[:n], dtype) for r in range(world)]) for i, (n, c) in enumerate(SLAB_CASES)]
     wants += [rank_sum([_inputs(r, 100 + k, 4096 * 32, dtype) for r in range(world)]) for k in range(3)]
-    extra = len(NORM_CASES) + 4                                  # the fused all-reduce + norm results: checked against the
+    extra = len(NORM_CASES) + 5                                  # the fused all-reduce + norm results: checked against the
     assert all(len(got[r]) == len(wants) + extra for r in range(world))   # unfused pair inside the workers; here: equal on every rank
     for j, want in enumerate(wants):
         for r in range(world):
@@ -176,6 +186,9 @@ def test_ranks_on_one_gpu_match_the_host_sum(dtype, world):
     for j in range(len(wants), len(wants) + extra):
         for r in range(1, world):
             np.testing.assert_array_equal(got[r][j], got[0][j], err_msg=f"rank {r}, fused call {j}")
+    full = np.concatenate([_inputs(r, 800, 37 * 1000, dtype).reshape(37, 1000) for r in range(world)], axis=1)
+    full[3] = 0.5
+    np.testing.assert_array_equal(got[0][len(wants) + len(NORM_CASES) + 4], full.argmax(axis=1).astype(np.float32))
     # the graph replays against the oracle: all-reduce in rank order, then the add + norm
     for k in range(2):
         summed = rank_sum([_inputs(r, 600 + k, 32 * 4096, dtype) for r in range(world)]).reshape(32, 4096)

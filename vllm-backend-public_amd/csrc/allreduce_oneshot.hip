@@ -31,7 +31,7 @@
 
 namespace mi355 {
 
-constexpr int kArMaxWorld = 8;
+constexpr int kArMaxWorld = 8;   // (ar_load_all / ar_wait_all name eight registers)
 constexpr int kArMaxBlocks = 256;
 constexpr int kArThreads = 256;
 constexpr long long kSpinLimitTicks = 200000000LL;   // 2 s of the 100 MHz wall clock
@@ -78,6 +78,20 @@ __device__ __forceinline__ ar_u32x4 ar_load_sys(const void* p) {   // the result
 }
 __device__ __forceinline__ void ar_wait_loads(ar_u32x4& r) {       // ties the value to the wait: no use can move above it
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(r)::"memory");
+}
+// The loads of one vector from every possible rank's slot and the wait that covers them, in straight-line
+// code: no branch lies between a load and its wait, so the compiler never has a reason to copy a destination
+// register before the data is in it (a copy made at a join of branches would carry the register's OLD value).
+// A rank that does not take part (p >= world, or p == skip) is asked for one fixed address; its value is unused.
+__device__ __forceinline__ void ar_load_all(ar_u32x4 (&in)[8], const unsigned char* slots, int64_t slot_bytes, int64_t byte_off,
+                                            int world, int skip) {
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+    in[p] = ar_load_sys((p < world && p != skip) ? slots + p * slot_bytes + byte_off : slots);
+}
+__device__ __forceinline__ void ar_wait_all(ar_u32x4 (&in)[8]) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(in[0]), "+v"(in[1]), "+v"(in[2]), "+v"(in[3]), "+v"(in[4]), "+v"(in[5]), "+v"(in[6]), "+v"(in[7])::"memory");
 }
 
 constexpr int kArVecPerThread = 2;   // 16-byte vectors a thread holds in flight per pass
@@ -200,9 +214,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int64_t v = v0 + min(tid + i * kArThreads, static_cast<int>(per) - 1);
-#pragma unroll
-        for (int p = 0; p < kArMaxWorld; ++p)
-          if (p < world && p != rank) in[i][p] = ar_load_sys(mine + p * slot_bytes + v * 16);
+        ar_load_all(in[i], mine, slot_bytes, v * 16, world, rank);
       }
       uint4* rr = reinterpret_cast<uint4*>(nm.residual + static_cast<int64_t>(b) * nm.res_stride);
 #pragma unroll
@@ -211,16 +223,13 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
         float acc[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        ar_wait_all(in[i]);
 #pragma unroll
         for (int p = 0; p < kArMaxWorld; ++p) {
           if (p < world) {
             float g[8];
-            if (p == rank) {
-              unpack8<T>(own[i], g);                   // (a thread beyond the row holds nothing: its values go nowhere)
-            } else {
-              ar_wait_loads(in[i][p]);
-              unpack8<T>(make_uint4(in[i][p].x, in[i][p].y, in[i][p].z, in[i][p].w), g);
-            }
+            const bool mine_p = p == rank;            // (a thread beyond the row holds nothing: its values go nowhere)
+            unpack8<T>(mine_p ? own[i] : make_uint4(in[i][p].x, in[i][p].y, in[i][p].z, in[i][p].w), g);
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc[q] += g[q];
           }
@@ -265,9 +274,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
 #pragma unroll
       for (int j = 0; j < kArVecPerThread; ++j) {
         const int64_t v = min(vb + j * kArThreads, v1 - 1);        // clamped: a surplus load re-reads the last vector
-#pragma unroll
-        for (int p = 0; p < kArMaxWorld; ++p)
-          if (p < world) in[j][p] = ar_load_sys(mine + p * slot_bytes + v * 16);
+        ar_load_all(in[j], mine, slot_bytes, v * 16, world, -1);
       }
 #pragma unroll
       for (int j = 0; j < kArVecPerThread; ++j) {
@@ -275,10 +282,10 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
         float acc[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        ar_wait_all(in[j]);
 #pragma unroll
         for (int p = 0; p < kArMaxWorld; ++p) {
           if (p < world) {
-            ar_wait_loads(in[j][p]);
             float f[8];
             unpack8<T>(make_uint4(in[j][p].x, in[j][p].y, in[j][p].z, in[j][p].w), f);
 #pragma unroll
@@ -297,6 +304,89 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
       __hip_atomic_store(rounds, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+// Max-reduce of one 64-bit key per row (the greedy pick of a vocabulary-sharded step: every rank holds the
+// (logit, index) key of its slice's best token, mi355_argmax_shard_key) and the token ids of the winners, in
+// ONE workgroup: thread t delivers key t to the peers' slots, the flags of chunk 0 say when theirs are here,
+// the max is taken over the ranks (signed 64-bit, as the process group's MAX does) and the id -- the low word,
+// stored complemented so that the lower index wins a tie -- is written to out_ids (and out_ids2).  Same
+// rounds, parities and bounded waits as the sum kernel; the own key stays in a register.
+typedef unsigned int ar_u32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(kArThreads) void allreduce_oneshot_max_keys_kernel(
+    const int64_t* __restrict__ keys, int64_t* __restrict__ out_ids, int64_t* __restrict__ out_ids2, int rows,
+    ArPeers peers, int rank, int world, int64_t max_bytes, unsigned* __restrict__ rounds, unsigned* __restrict__ error) {
+  const int tid = threadIdx.x;
+  const unsigned round = __hip_atomic_load(rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  const int parity = round & 1;
+  const int64_t flags_off = ar_flags_offset(world, max_bytes);
+  const int64_t slot_off = (static_cast<int64_t>(parity) * world + rank) * max_bytes;
+  const int t = min(tid, rows - 1);                    // surplus threads repeat the last row (same value, same place)
+  const int64_t mine = MI355_LD(int64_t, keys, keys + t);
+  const ar_u32x2 mv = {static_cast<unsigned>(static_cast<unsigned long long>(mine) & 0xFFFFFFFFull),
+                       static_cast<unsigned>(static_cast<unsigned long long>(mine) >> 32)};
+  for (int p = 0; p < world; ++p)
+    if (p != rank) {
+      void* dst = peers.buf[p] + slot_off + t * 8;
+      asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(mv) : "memory");
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid < world && tid != rank) {
+    unsigned* flag = reinterpret_cast<unsigned*>(peers.buf[tid] + flags_off) + rank * kArMaxBlocks;
+    __hip_atomic_store(flag, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __shared__ int ok_s;
+  if (tid == 0) ok_s = 1;
+  __syncthreads();
+  if (tid < world && tid != rank) {
+    const unsigned* flag = reinterpret_cast<const unsigned*>(peers.buf[rank] + flags_off) + tid * kArMaxBlocks;
+    const long long t0 = wall_clock64();
+    bool ok = true;
+    while (static_cast<int>(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - round) < 0) {
+      if (wall_clock64() - t0 > kSpinLimitTicks) {
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (!ok) {
+      ok_s = 0;
+      atomicExch(error, 1u + static_cast<unsigned>(tid));
+    }
+  }
+  __syncthreads();
+  if (ok_s != 0) {                                     // a timed-out wait leaves the outputs as they were
+    const unsigned char* slots = peers.buf[rank] + static_cast<int64_t>(parity) * world * max_bytes;
+    // straight-line: a load for every possible rank (a slot that does not take part: one fixed address, its value
+    // unused), one wait, selects -- no branch between a load and the wait that covers it, so the compiler has no
+    // reason to copy a destination register before its data has arrived
+    ar_u32x2 in[kArMaxWorld];
+#pragma unroll
+    for (int p = 0; p < kArMaxWorld; ++p) {
+      const bool peer = p < world && p != rank;
+      const void* src = peer ? static_cast<const void*>(slots + p * max_bytes + t * 8) : static_cast<const void*>(slots);
+      asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=v"(in[p]) : "v"(src) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(in[0]), "+v"(in[1]), "+v"(in[2]), "+v"(in[3]), "+v"(in[4]), "+v"(in[5]), "+v"(in[6]), "+v"(in[7])::"memory");
+    static_assert(kArMaxWorld == 8, "the wait above names eight registers");
+    int64_t best = mine;
+#pragma unroll
+    for (int p = 0; p < kArMaxWorld; ++p) {
+      const bool peer = p < world && p != rank;
+      const int64_t k = static_cast<int64_t>((static_cast<unsigned long long>(in[p].y) << 32) | in[p].x);
+      best = (peer && k > best) ? k : best;
+    }
+    if (tid < rows) {
+      const int64_t idx = static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(static_cast<unsigned long long>(best) & 0xFFFFFFFFull));
+      MI355_ST(int64_t, out_ids, out_ids + tid, idx);
+      if (out_ids2 != nullptr) MI355_ST(int64_t, out_ids2, out_ids2 + tid, idx);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(rounds, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one workgroup: it is the last
 }
 
 }  // namespace mi355
@@ -428,6 +518,26 @@ extern "C" int32_t mi355_allreduce_oneshot_run_add_norm(void* comm, const void* 
                   residual_stride, out_stride, hidden, eps};
   return allreduce_oneshot_launch(name, comm, const_cast<void*>(data), slabs, slabs ? num_slabs : 0,
                                   static_cast<int64_t>(rows) * hidden, dtype, stream, &nm, rows);
+}
+
+extern "C" int32_t mi355_allreduce_oneshot_run_max_keys(void* comm, const int64_t* keys, int64_t* out_ids,
+                                                        int64_t* out_ids2, int32_t rows, void* stream) {
+  using namespace mi355;
+  const char* name = "mi355_allreduce_oneshot_run_max_keys";
+  MI355_REQUIRE(comm && keys && out_ids, MI355_ERR_INVALID, "%s: null pointer", name);
+  ArComm* c = static_cast<ArComm*>(comm);
+  MI355_REQUIRE(c->connected, MI355_ERR_INVALID, "%s: not connected (exchange the handles first)", name);
+  MI355_REQUIRE(rows >= 0 && rows <= kArThreads && static_cast<int64_t>(rows) * 8 <= c->max_bytes, MI355_ERR_UNSUPPORTED,
+                "%s: rows %d outside [0, %d]", name, rows, kArThreads);
+  MI355_REQUIRE((reinterpret_cast<uintptr_t>(keys) & 7) == 0 && (reinterpret_cast<uintptr_t>(out_ids) & 7) == 0 &&
+                    (reinterpret_cast<uintptr_t>(out_ids2) & 7) == 0,
+                MI355_ERR_INVALID, "%s: pointers must be 8-byte aligned", name);
+  if (rows == 0) return MI355_OK;
+  ArPeers peers;
+  for (int p = 0; p < kArMaxWorld; ++p) peers.buf[p] = c->peer[p < c->world ? p : c->rank];
+  hipLaunchKernelGGL(allreduce_oneshot_max_keys_kernel, dim3(1), dim3(kArThreads), 0, static_cast<hipStream_t>(stream), keys,
+                     out_ids, out_ids2, rows, peers, c->rank, c->world, c->max_bytes, c->rounds, c->error);
+  return check_launch(name);
 }
 
 extern "C" int32_t mi355_allreduce_oneshot_status_async(void* comm, uint32_t* host_word, void* stream) {

@@ -116,6 +116,21 @@ class OneShotAllReduce:
             rows, hidden, float(eps), _DT[residual.dtype], _stream()))
         return out
 
+    MAX_KEY_ROWS = 256
+
+    def run_max_keys(self, keys: torch.Tensor, out_ids: torch.Tensor, out_ids2: torch.Tensor | None = None) -> torch.Tensor:
+        """Token ids of the max over the ranks of one (logit, index) key per row (ops.argmax_shard_key): the MAX
+        all-reduce of the keys and ops.argmax_key_to_index in one launch; `out_ids2`: a second destination."""
+        n = keys.numel()
+        for t, name in ((keys, "keys"), (out_ids, "out_ids"), (out_ids2, "out_ids2")):
+            if t is not None and (not t.is_cuda or t.dtype != torch.int64 or not t.is_contiguous() or t.numel() < n):
+                raise ValueError(f"{name} must be a contiguous int64 GPU tensor of one element per row")
+        if not 0 < n <= self.MAX_KEY_ROWS:
+            raise ValueError(f"one-shot key reduction takes 1 .. {self.MAX_KEY_ROWS} rows")
+        check(lib.mi355_allreduce_oneshot_run_max_keys(self._comm, keys.data_ptr(), out_ids.data_ptr(),
+                                                       out_ids2.data_ptr() if out_ids2 is not None else 0, n, _stream()))
+        return out_ids
+
     def check(self) -> None:
         """Synchronises with the queued work; raises if a wait of any call so far timed out."""
         check(lib.mi355_allreduce_oneshot_status(self._comm))

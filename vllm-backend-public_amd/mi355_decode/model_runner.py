@@ -108,6 +108,7 @@ class ModelRunner:
         self.oneshot = None                           # collectives.OneShotAllReduce, set by build_engine (opt-in)
         self.oneshot_calls = 0
         self.fused_allreduce_norms = 0                # ... of which all-reduce + residual add + norm in one launch
+        self.oneshot_key_reductions = 0               # greedy picks of a vocabulary-sharded step reduced by the one-shot kernel
         self.oneshot_fallbacks = 0                    # set-ups that ended on the process group's all-reduce instead
         self._no_collectives = False                  # True while GEMM forms are timed (tune)
         self.decode_splits = decode_splits
@@ -684,6 +685,12 @@ class ModelRunner:
         keys = self.keys[: logits.shape[0]] if logits.shape[0] <= self.keys.numel() else \
             torch.empty(logits.shape[0], dtype=torch.int64, device=self.device)
         ops.argmax_shard_key(logits, self.vocab_offset, out=keys)
+        if (self.oneshot is not None and self.tp_size > 1 and not self._no_collectives
+                and logits.shape[0] <= self.oneshot.MAX_KEY_ROWS):
+            # the keys' max over the ranks and the winners' ids in one launch of the one-shot kernel
+            self.oneshot.run_max_keys(keys, out, ids_out)
+            self.oneshot_key_reductions += 1
+            return
         self._allreduce_max(keys)
         ops.argmax_key_to_index(keys, out=out)
         if ids_out is not None:
