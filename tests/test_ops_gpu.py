@@ -1436,8 +1436,22 @@ def test_paged_attn_decode_fused(ops, dtype, nh, kvh, d, splits, slabs):
     """One launch == rope_kv_write followed by paged_attn_decode: the attention output, the
     K pages and the V pages are bit-identical, from 16-bit rows (slabs == 0) and from fp32
     partial-sum slabs + bias; and the output matches the oracle."""
-    rng = rng_for("dec-fused", dtype, nh, kvh, d, splits, slabs)
-    ctxs = [1, 16, 17, 33, 128, 129, 200, 255, 513, 0, 64]
+    _check_decode_fused(ops, dtype, nh, kvh, d, splits, slabs, [1, 16, 17, 33, 128, 129, 200, 255, 513, 0, 64])
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("nh,kvh,d,splits,slabs", [(32, 8, 128, 1, 0), (32, 8, 128, 1, 4), (32, 8, 128, 2, 0), (16, 8, 64, 1, 2)])
+def test_paged_attn_decode_more_workgroups_than_cus(ops, dtype, nh, kvh, d, splits, slabs):
+    """More than 256 workgroups (sequences x kv heads x splits: a wide batch): the launch takes the form with ONE
+    register stage of K/V per wave, two workgroups to a CU.  Same checks as above, on 44 sequences, and the plain
+    kernel against the oracle on its own."""
+    ctxs = [1, 16, 17, 33, 128, 129, 200, 255, 513, 0, 64, 300, 31, 1000, 2, 100, 257, 640, 48, 15, 96, 191] * 2
+    assert len(ctxs) * kvh * splits > 256
+    _check_decode_fused(ops, dtype, nh, kvh, d, splits, slabs, ctxs)
+
+
+def _check_decode_fused(ops, dtype, nh, kvh, d, splits, slabs, ctxs):
+    rng = rng_for("dec-fused", dtype, nh, kvh, d, splits, slabs, len(ctxs))
     n = len(ctxs)
     kc, vc, bt = build_paged(rng, ctxs, kvh, d, dtype, poison=False)
     width = (nh + 2 * kvh) * d

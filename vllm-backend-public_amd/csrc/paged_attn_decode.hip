@@ -67,7 +67,7 @@ constexpr int kDecodeWaves = kDecodeThreads / 64;
 constexpr int kStep = 32;  // tokens per wave step (two 16-token pages)
 // Register sets of K/V tiles per wave: the loads of a wave's next step are in flight while it
 // computes one (measured at contexts 129-255: 13.6 vs 15.2 us; three sets were slower again).
-constexpr int kStages = 2;
+constexpr int kMaxStages = 2;
 
 template <int KS, int NT>
 struct KVRegs {
@@ -157,7 +157,7 @@ __device__ __forceinline__ void rotate8(const float (&x1)[8], const float (&x2)[
   }
 }
 
-template <typename T, int D, int FUSE, int SLABS, bool SPLIT>
+template <typename T, int D, int FUSE, int SLABS, bool SPLIT, int kStages>
 __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
     uint16_t* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_ml,
     const uint16_t* __restrict__ q, int64_t q_stride, uint16_t* k_cache,
@@ -563,16 +563,23 @@ static int32_t launch_decode(void* out, const void* q, int64_t q_stride, void* k
     part_ml = part_o + static_cast<int64_t>(num_seqs) * num_heads * num_splits * D;
   }
   dim3 grid(num_seqs, num_kv_heads, num_splits), block(kDecodeThreads);
-  if (num_splits == 1)
-    hipLaunchKernelGGL((paged_attn_decode_kernel<T, D, FUSE, SLABS, false>), grid, block, 0, s,
-                       static_cast<uint16_t*>(out), part_o, part_ml, static_cast<const uint16_t*>(q), q_stride,
-                       static_cast<uint16_t*>(k_cache), static_cast<uint16_t*>(v_cache), num_blocks, block_tables,
-                       max_blocks, context_lens, num_heads, num_kv_heads, scale * 1.4426950408889634f, num_splits, ra);
-  else
-    hipLaunchKernelGGL((paged_attn_decode_kernel<T, D, FUSE, SLABS, true>), grid, block, 0, s,
-                       static_cast<uint16_t*>(out), part_o, part_ml, static_cast<const uint16_t*>(q), q_stride,
-                       static_cast<uint16_t*>(k_cache), static_cast<uint16_t*>(v_cache), num_blocks, block_tables,
-                       max_blocks, context_lens, num_heads, num_kv_heads, scale * 1.4426950408889634f, num_splits, ra);
+  // Register stages of K/V per wave.  Two (the next step's loads in flight while one is computed) cost the
+  // registers that would let a second workgroup share the CU: worth it while the launch has at most one
+  // workgroup per CU and each must hide its own latencies; with more workgroups than CUs (128 sequences x 8 kv
+  // heads: four rounds) one stage and two workgroups per CU is faster -- 30.9 vs 37.7 us at 128 x 192 tokens,
+  // 58.4 vs 70.9 us at 256 x 192.
+  const bool one_stage = static_cast<int64_t>(num_seqs) * num_kv_heads * num_splits > 256;
+#define MI355_PAD_LAUNCH(SPLIT_, STG_)                                                                             \
+  hipLaunchKernelGGL((paged_attn_decode_kernel<T, D, FUSE, SLABS, SPLIT_, STG_>), grid, block, 0, s,               \
+                     static_cast<uint16_t*>(out), part_o, part_ml, static_cast<const uint16_t*>(q), q_stride,      \
+                     static_cast<uint16_t*>(k_cache), static_cast<uint16_t*>(v_cache), num_blocks, block_tables,   \
+                     max_blocks, context_lens, num_heads, num_kv_heads, scale * 1.4426950408889634f, num_splits, ra)
+  if (num_splits == 1) {
+    if (one_stage) MI355_PAD_LAUNCH(false, 1); else MI355_PAD_LAUNCH(false, kMaxStages);
+  } else {
+    if (one_stage) MI355_PAD_LAUNCH(true, 1); else MI355_PAD_LAUNCH(true, kMaxStages);
+  }
+#undef MI355_PAD_LAUNCH
   int32_t rc = check_launch("mi355_paged_attn_decode");
   if (rc != MI355_OK || num_splits == 1) return rc;
   hipLaunchKernelGGL((paged_attn_merge_kernel<T, D>), dim3(num_seqs * num_heads), dim3(D), 0, s,
