@@ -148,7 +148,8 @@ class OneShotAllReduce:
 
     def self_test(self, device) -> bool:
         """A known-answer all-reduce through the mapped buffers, at two sizes and on both slot parities,
-        plain and from slabs.  True if this rank saw the exact sums and no wait timed out."""
+        plain and from slabs, then through the add + norm and the key back ends.  True if this rank saw the exact
+        results and no wait timed out."""
         try:
             ok = True
             for count in (8 * self.world, min(self.max_bytes // 2, 1 << 19)):
@@ -163,6 +164,24 @@ class OneShotAllReduce:
                     out = torch.zeros(count, dtype=torch.bfloat16, device=device)
                     self.run_slabs(s, 2, out)
                     ok &= bool((out == 0.5 * want).all().item())
+            # the add + norm back end: residual 0, weight 1, every rank's rows constant r + 1 -> the summed row is the
+            # constant W (W + 1) / 2, its norm round(c * rsqrt(c * c + eps)); and the key back end: rank r offers the
+            # key (r + 1) << 32 | ~(100 * r + row) for every row, the last rank's wins
+            rows, hidden = 4, 1024
+            if self.fits_add_norm(rows, hidden, torch.bfloat16):
+                for _ in range(2):
+                    data = torch.full((rows, hidden), float(self.rank + 1), dtype=torch.bfloat16, device=device)
+                    resid = torch.zeros(rows, hidden, dtype=torch.bfloat16, device=device)
+                    x = torch.zeros(rows, hidden, dtype=torch.bfloat16, device=device)
+                    self.run_add_norm(resid, torch.ones(hidden, dtype=torch.bfloat16, device=device), 1e-5, x, data=data)
+                    c = self.world * (self.world + 1) / 2.0
+                    want_x = torch.tensor(c, dtype=torch.float32).mul(torch.rsqrt(torch.tensor(c * c + 1e-5))).to(torch.bfloat16)
+                    ok &= bool((resid == c).all().item()) and bool((x.float() - want_x.float()).abs().max().item() <= 2 ** -7)
+                    keys = torch.tensor([((self.rank + 1) << 32) | (0xFFFFFFFF - (100 * self.rank + i)) for i in range(rows)],
+                                        dtype=torch.int64, device=device)
+                    ids = torch.full((rows,), -1, dtype=torch.int64, device=device)
+                    self.run_max_keys(keys, ids)
+                    ok &= ids.tolist() == [100 * (self.world - 1) + i for i in range(rows)]
             self.check()
             return ok
         except Mi355Error as exc:
