@@ -155,6 +155,11 @@ def build_engine(args: EngineArgs, state_dict: Optional[dict] = None, model_conf
         else:
             log.info("rank %d: one-shot all-reduce for messages up to %d bytes (self-test passed on all %d ranks)",
                      rank, runner.oneshot.max_bytes, tp)
+    if (not graphs and not args.enforce_eager and tp > 1 and runner.oneshot is not None
+            and runner.decode_collectives_one_shot()):
+        # no process-group call is left in a decode step (every all-reduce and the greedy pick's key reduction
+        # run on the one-shot kernel): the step can be captured whatever the process group's backend is
+        runner.use_graphs = graphs = True
     if os.environ.get("MI355_LAZY_TUNE", "0") != "1":
         runner.warm_up()                              # every rank, same order: the choices are broadcast
     log.info("tensor-parallel rank %d of %d on %s: %d layers, MLP %s, lm_head %s, %d KV pages, HIP graphs %s, %s",

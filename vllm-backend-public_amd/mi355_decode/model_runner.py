@@ -750,6 +750,13 @@ class ModelRunner:
         by_len = max(1, self.max_model_len // 256)      # keep >= 2 wave-steps per workgroup
         return max(1, min(want, by_len, self._max_splits))
 
+    def decode_collectives_one_shot(self) -> bool:
+        """True if every collective of a decode step of this runner, at any batch size it takes, runs on the
+        one-shot kernel: the all-reduces (fused with the add + norm behind them) and, with a sharded vocabulary,
+        the greedy pick's key reduction."""
+        return (self.tp_size > 1 and self.oneshot is not None and self._allreduce_norm_fused(self.max_num_seqs)
+                and (not self.vocab_sharded or self.max_num_seqs <= self.oneshot.MAX_KEY_ROWS))
+
     def _allreduce_norm_fused(self, b: int) -> bool:
         """True if the all-reduce behind o_proj / down_proj of a b-row decode step runs together with the residual
         add + norm that follows it (the one-shot kernel's add + norm form: one launch instead of two)."""
