@@ -24,6 +24,18 @@ SLAB_CASES = [(2, 4096 * 16), (8, 4096 * 128), (3, 1000 * 8), (4, 4096 * 256)]  
 NORM_CASES = [(32, 4096, 0), (128, 4096, 4), (256, 4096, 0), (16, 8192, 2), (5, 3584, 0), (7, 1000, 1)]   # (rows, hidden, slabs)
 
 
+def _sizes(world):
+    """Eight ranks SHARE the test box's one GPU: a call's workgroups (one per 8 KB or per row, on every rank) spin
+    until their chunk has arrived from every rank, so all ranks' workgroups of a call must be resident at once --
+    on one card that caps the messages of an 8-rank call (256 KiB: 8 x 32 workgroups); a rank with a GPU of its
+    own has room for the largest call (256 workgroups)."""
+    if world < 8:
+        return COUNTS, SLAB_CASES, NORM_CASES
+    cap = 4096 * 32
+    return ([min(c, cap) for c in COUNTS], [(n, min(c, cap)) for n, c in SLAB_CASES],
+            [(min(r, 32), h, n) for r, h, n in NORM_CASES])
+
+
 def _slabs(rank, i, n, count):
     rng = np.random.Generator(np.random.PCG64(77000 + 1000 * i + rank))
     return (rng.standard_normal((n, count)) * (1 + rank)).astype(np.float32)
@@ -62,12 +74,13 @@ def _worker(rank, world, conns, dtype, out_q):
         ar = OneShotAllReduce(max_bytes=1 << 21, rank=rank, world=world, exchange=exchange)
         assert ar.self_test("cuda"), "the known-answer self-test failed"
         results = []
-        for i, count in enumerate(COUNTS):                       # eager calls, sizes changing from call to call
+        COUNTS_W, SLAB_CASES_W, NORM_CASES_W = _sizes(world)
+        for i, count in enumerate(COUNTS_W):                     # eager calls, sizes changing from call to call
             t = T.from_numpy(_inputs(rank, i, count, dtype)).to(tdt).cuda()
             ar.run(t)
             results.append(t.float().cpu().numpy())
         ar.check()
-        for i, (n, count) in enumerate(SLAB_CASES):              # this rank's message formed from fp32 slabs in the launch
+        for i, (n, count) in enumerate(SLAB_CASES_W):            # this rank's message formed from fp32 slabs in the launch
             sl = T.from_numpy(_slabs(rank, i, n + 1, count)).cuda()          # one slab more than is summed
             out = T.full((count,), 3.0, dtype=tdt, device="cuda")
             ar.run_slabs(sl, n, out)
@@ -92,7 +105,7 @@ def _worker(rank, world, conns, dtype, out_q):
         # the all-reduce with the residual add + RMSNorm behind it in one launch: bit-identical to the all-reduce
         # (from 16-bit rows or from slabs) followed by the add + norm kernel, eagerly and replayed from a graph
         from mi355_decode import ops
-        for i, (rows, hidden, n) in enumerate(NORM_CASES):
+        for i, (rows, hidden, n) in enumerate(NORM_CASES_W):
             count = rows * hidden
             w = T.from_numpy(_inputs(0, 300 + i, hidden, dtype)).to(tdt).cuda()           # the same norm weight on every rank
             resid0 = T.from_numpy(_inputs(0, 400 + i, count, dtype)).to(tdt).cuda().view(rows, hidden)
@@ -148,8 +161,7 @@ def _worker(rank, world, conns, dtype, out_q):
         out_q.put((rank, "error", traceback.format_exc() + repr(exc)))
 
 
-@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("dtype,world", [("bfloat16", 2), ("float16", 2), ("bfloat16", 4), ("float16", 4), ("bfloat16", 8)])
 def test_ranks_on_one_gpu_match_the_host_sum(dtype, world):
     ctx = mp.get_context("spawn")
     pipes = [ctx.Pipe() for _ in range(world - 1)]
@@ -161,7 +173,7 @@ def test_ranks_on_one_gpu_match_the_host_sum(dtype, world):
     got = {}
     try:
         for _ in procs:
-            rank, status, payload = q.get(timeout=90)
+            rank, status, payload = q.get(timeout=90 if world < 8 else 150)
             assert status == "ok", payload
             got[rank] = payload
     finally:
@@ -175,8 +187,9 @@ def test_ranks_on_one_gpu_match_the_host_sum(dtype, world):
             acc = acc + part.astype(np.float32)
         return R.round_to(acc, dtype)
 
-    wants = [rank_sum([_inputs(r, i, c, dtype) for r in range(world)]) for i, c in enumerate(COUNTS)]
-    wants += [rank_sum([_slab_sum(_slabs(r, i, n + 1, c)[:n], dtype) for r in range(world)]) for i, (n, c) in enumerate(SLAB_CASES)]
+    counts, slab_cases, _ = _sizes(world)
+    wants = [rank_sum([_inputs(r, i, c, dtype) for r in range(world)]) for i, c in enumerate(counts)]
+    wants += [rank_sum([_slab_sum(_slabs(r, i, n + 1, c)[:n], dtype) for r in range(world)]) for i, (n, c) in enumerate(slab_cases)]
     wants += [rank_sum([_inputs(r, 100 + k, 4096 * 32, dtype) for r in range(world)]) for k in range(3)]
     extra = len(NORM_CASES) + 5                                  # the fused all-reduce + norm results: checked against the
     assert all(len(got[r]) == len(wants) + extra for r in range(world))   # unfused pair inside the workers; here: equal on every rank
