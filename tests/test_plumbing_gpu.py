@@ -80,6 +80,7 @@ def test_harness_plumbing_pass(tmp_path, case, tp):
         env[e["name"]] = e["value"]
     if tp > 1:
         env["MI355_DIST_BACKEND"] = "gloo"
+        env["MI355_ONESHOT_ALLREDUCE"] = "1"     # the production form of the step: one-shot collectives inside HIP graphs
     log = open(tmp_path / "server.log", "w")
     proc = subprocess.Popen([sys.executable, "-m", "mi355_decode.entrypoints.openai.api_server"] + args,
                             env=env, stdout=log, stderr=subprocess.STDOUT, start_new_session=True)
@@ -145,6 +146,8 @@ def test_harness_plumbing_pass(tmp_path, case, tp):
         for r in range(tp):                           # every rank really came up, with the sharding its size implies
             assert f"tensor-parallel rank {r} of {tp}" in text, text[-2000:]
         assert ("MLP sharded, lm_head sharded" in text) == (tp > 1)
+        if tp > 1:
+            assert text.count("HIP graphs on") == tp and "one-shot all-reduce for messages up to" in text, text[-2000:]
     finally:
         proc.terminate()
         try:
