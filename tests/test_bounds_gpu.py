@@ -33,4 +33,4 @@ def test_no_access_leaves_its_allocation():
     res = json.loads(p.stdout.strip().splitlines()[-1])
     print(json.dumps(res, indent=1))
     assert res["negative_control"]["refused"] > 0
-    assert len(res["rank_steps"]) == 16 and len(res["engine"]) == 3 and len(res["sampler"]) == 12
+    assert len(res["rank_steps"]) == 18 and len(res["engine"]) == 3 and len(res["sampler"]) == 12

@@ -31,6 +31,9 @@ CASES = [
     ("cfg2_mlp_sharded", "llama-3-8b", 4, 2, 128, 200, 256, True, False),
     # the 8-GPU point of the scaling run (bench.py --gpus 8: batch 32 per GPU): 256 rows on a TP8 rank's slices
     ("cfg2_tp8_256rows", "llama-3-8b", 8, 3, 256, 200, 256, True, False),
+    # one GPU at 136 sequences (the harness's deployment default allows 256 at a time): 129+ GEMM rows, and
+    # 1088 (sequence, kv head) groups -- the decode attention's one-wave-per-group form
+    ("one_gpu_136rows", "llama-3-8b", 1, 0, 136, 200, 256, False, False),
     ("cfg3", "llama-3-70b", 8, 5, 16, 2100, 2304, False, False),
     ("cfg3_mlp_sharded", "llama-3-70b", 8, 5, 16, 2100, 2304, True, False),
     ("cfg4_bf16", "qwen2-7b", 1, 0, 64, 700, 1024, False, False),

@@ -1450,6 +1450,18 @@ def test_paged_attn_decode_more_workgroups_than_cus(ops, dtype, nh, kvh, d, spli
     _check_decode_fused(ops, dtype, nh, kvh, d, splits, slabs, ctxs)
 
 
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("nh,kvh,d,splits,slabs", [(32, 8, 128, 1, 0), (32, 8, 128, 1, 4), (32, 8, 128, 2, 1), (16, 8, 64, 1, 2),
+                                                   (40, 4, 128, 1, 0)])
+def test_paged_attn_decode_one_wave_per_group(ops, dtype, nh, kvh, d, splits, slabs):
+    """From 1024 (sequence, kv head, split) groups on, a launch gives every group ONE wave that walks all of its
+    32-token steps (no merge across waves).  Same checks as above on 132 or 264 sequences; the last case has 10
+    query heads per kv head, more than the one-wave prologue has threads for, and must take the four-wave form."""
+    ctxs = [1, 16, 17, 33, 128, 129, 200, 255, 513, 0, 64, 300, 31, 1000, 2, 100, 257, 640, 48, 15, 96, 191] * (6 if kvh == 8 else 12)
+    assert len(ctxs) * kvh * splits >= 1024
+    _check_decode_fused(ops, dtype, nh, kvh, d, splits, slabs, ctxs)
+
+
 def _check_decode_fused(ops, dtype, nh, kvh, d, splits, slabs, ctxs):
     rng = rng_for("dec-fused", dtype, nh, kvh, d, splits, slabs, len(ctxs))
     n = len(ctxs)

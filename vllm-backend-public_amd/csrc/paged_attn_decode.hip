@@ -40,6 +40,7 @@
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace mi355 {
 
@@ -63,7 +64,6 @@ __device__ unsigned long long g_attn_trace[4096 * 16];
 #endif
 
 constexpr int kDecodeThreads = 256;
-constexpr int kDecodeWaves = kDecodeThreads / 64;
 constexpr int kStep = 32;  // tokens per wave step (two 16-token pages)
 // Register sets of K/V tiles per wave: the loads of a wave's next step are in flight while it
 // computes one (measured at contexts 129-255: 13.6 vs 15.2 us; three sets were slower again).
@@ -157,8 +157,8 @@ __device__ __forceinline__ void rotate8(const float (&x1)[8], const float (&x2)[
   }
 }
 
-template <typename T, int D, int FUSE, int SLABS, bool SPLIT, int kStages>
-__global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
+template <typename T, int D, int FUSE, int SLABS, bool SPLIT, int kStages, int NW>
+__global__ __launch_bounds__(64 * NW) void paged_attn_decode_kernel(
     uint16_t* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_ml,
     const uint16_t* __restrict__ q, int64_t q_stride, uint16_t* k_cache,
     uint16_t* v_cache, int num_blocks, const int32_t* __restrict__ block_tables,
@@ -216,9 +216,9 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
 #ifdef MI355_ATTN_TRACE
   if (ctx >= 0) MI355_STAMP(1);
 #endif
-  // token range of this split: multiples of one workgroup pass (4 waves x 32)
+  // token range of this split: multiples of one workgroup pass (NW waves x 32)
   int per_split = (ctx + num_splits - 1) / num_splits;
-  per_split = (per_split + kStep * kDecodeWaves - 1) / (kStep * kDecodeWaves) * (kStep * kDecodeWaves);
+  per_split = (per_split + kStep * NW - 1) / (kStep * NW) * (kStep * NW);
   const int t_begin = split * per_split;
   const int t_end = min(ctx, t_begin + per_split);
 
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
       issue_loads(kv[0], tb);
     }
 #pragma unroll
-    for (int j = 1; j < kStages; ++j) issue_loads(kv[j], tb + j * kStep * kDecodeWaves);
+    for (int j = 1; j < kStages; ++j) issue_loads(kv[j], tb + j * kStep * NW);
   };
 
   // Q fragments (B operand): column c = head within the group
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
   MI355_WAIT_ALL();
   MI355_STAMP(3);                                     // every K/V load issued so far has arrived
 #endif
-  if (t_begin + kStages * kStep * kDecodeWaves >= t_end) {
+  if (t_begin + kStages * kStep * NW >= t_end) {
     // Every step of the range is already in a first stage of some wave (contexts up to 256 tokens without
     // splits): nothing more to load.  Workgroup-uniform, and this side holds no load at all: the look-ups of
     // the block table (a scalar round trip each) and the one-address loads the general loop issues for steps
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
 #pragma unroll
     for (int j = 0; j < kStages; ++j) {
       if (tb < t_end) step(kv[j], tb);
-      tb += kStep * kDecodeWaves;
+      tb += kStep * NW;
     }
   } else {
     while (tb < t_end) {
@@ -466,8 +466,8 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
         if (tb < t_end) {
           step(kv[j], tb);
         }
-        issue_loads(kv[j], tb + kStages * kStep * kDecodeWaves);
-        tb += kStep * kDecodeWaves;
+        issue_loads(kv[j], tb + kStages * kStep * NW);
+        tb += kStep * NW;
       }
     }
   }
@@ -480,9 +480,9 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
   l += __shfl_xor(l, 32, 64);
 
   // ---- merge the 4 waves through LDS: O as [wave][d][16 heads]
-  __shared__ float lds_o[kDecodeWaves][D * 16];
-  __shared__ float lds_m[kDecodeWaves][16];
-  __shared__ float lds_l[kDecodeWaves][16];
+  __shared__ float lds_o[NW][D * 16];
+  __shared__ float lds_m[NW][16];
+  __shared__ float lds_l[NW][16];
 #pragma unroll
   for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -495,15 +495,15 @@ __global__ __launch_bounds__(kDecodeThreads) void paged_attn_decode_kernel(
   MI355_STAMP(5);
 
   // two adjacent head_dim elements per thread: one pass for a group of 4 heads of 128
-  for (int idx = threadIdx.x; idx < group * (D / 2); idx += kDecodeThreads) {
+  for (int idx = threadIdx.x; idx < group * (D / 2); idx += 64 * NW) {
     const int hh = idx / (D / 2), d = 2 * (idx % (D / 2));
     float mg = lds_m[0][hh];
 #pragma unroll
-    for (int w = 1; w < kDecodeWaves; ++w) mg = fmaxf(mg, lds_m[w][hh]);
+    for (int w = 1; w < NW; ++w) mg = fmaxf(mg, lds_m[w][hh]);
     float acc0 = 0.f, acc1 = 0.f, lsum = 0.f;
     if (mg != -INFINITY) {
 #pragma unroll
-      for (int w = 0; w < kDecodeWaves; ++w) {
+      for (int w = 0; w < NW; ++w) {
         const float f = exp2f(lds_m[w][hh] - mg);
         acc0 += f * lds_o[w][d * 16 + hh];
         acc1 += f * lds_o[w][(d + 1) * 16 + hh];
@@ -562,23 +562,38 @@ static int32_t launch_decode(void* out, const void* q, int64_t q_stride, void* k
     part_o = static_cast<float*>(workspace);
     part_ml = part_o + static_cast<int64_t>(num_seqs) * num_heads * num_splits * D;
   }
-  dim3 grid(num_seqs, num_kv_heads, num_splits), block(kDecodeThreads);
-  // Register stages of K/V per wave.  Two (the next step's loads in flight while one is computed) cost the
-  // registers that would let a second workgroup share the CU: worth it while the launch has at most one
-  // workgroup per CU and each must hide its own latencies; with more workgroups than CUs (128 sequences x 8 kv
-  // heads: four rounds) one stage and two workgroups per CU is faster -- 30.9 vs 37.7 us at 128 x 192 tokens,
-  // 58.4 vs 70.9 us at 256 x 192.
-  const bool one_stage = static_cast<int64_t>(num_seqs) * num_kv_heads * num_splits > 256;
-#define MI355_PAD_LAUNCH(SPLIT_, STG_)                                                                             \
-  hipLaunchKernelGGL((paged_attn_decode_kernel<T, D, FUSE, SLABS, SPLIT_, STG_>), grid, block, 0, s,               \
+  // Waves per (sequence, kv head, split) and register stages of K/V per wave.  Two stages (the next step's
+  // loads in flight while one is computed) cost the registers that would let a second workgroup share the CU:
+  // worth it while the launch has at most one workgroup per CU and each must hide its own latencies; with more
+  // workgroups than CUs (128 sequences x 8 kv heads: four rounds) one stage and two workgroups per CU is
+  // faster -- 30.9 vs 37.7 us at 128 x 192 tokens, 58.4 vs 70.9 us at 256 x 192.  From 1024 groups on there
+  // is a wave for every SIMD without splitting a group's tokens over four: ONE wave per group walks all of
+  // its steps, nothing is merged across waves and eight groups share a CU -- 29.6 vs 31.0 us at 128 x 192
+  // tokens in the step, 54.2 vs 58.5 us at 256 x 192 (at 512 groups it is the slower form: 18.9 vs 17.2 us).
+  // MI355_ATTN_FORM = 42 / 41 / 11 (waves * 10 + stages) forces one form, for measurements.
+  const int64_t wgs = static_cast<int64_t>(num_seqs) * num_kv_heads * num_splits;
+  const bool one_wave_fits = (num_heads / num_kv_heads + 1) * (D / 16) + D / 8 <= 64;   // the prologue's threads
+  int form = wgs >= 1024 && one_wave_fits ? 11 : wgs > 256 ? 41 : 42;
+  static const int forced = [] { const char* e = getenv("MI355_ATTN_FORM"); return e ? atoi(e) : 0; }();
+  if (forced == 41 || forced == 42 || (forced == 11 && one_wave_fits)) form = forced;
+  dim3 grid(num_seqs, num_kv_heads, num_splits), block(form / 10 == 1 ? 64 : kDecodeThreads);
+#define MI355_PAD_LAUNCH(SPLIT_, STG_, NW_)                                                                        \
+  hipLaunchKernelGGL((paged_attn_decode_kernel<T, D, FUSE, SLABS, SPLIT_, STG_, NW_>), grid, block, 0, s,          \
                      static_cast<uint16_t*>(out), part_o, part_ml, static_cast<const uint16_t*>(q), q_stride,      \
                      static_cast<uint16_t*>(k_cache), static_cast<uint16_t*>(v_cache), num_blocks, block_tables,   \
                      max_blocks, context_lens, num_heads, num_kv_heads, scale * 1.4426950408889634f, num_splits, ra)
-  if (num_splits == 1) {
-    if (one_stage) MI355_PAD_LAUNCH(false, 1); else MI355_PAD_LAUNCH(false, kMaxStages);
-  } else {
-    if (one_stage) MI355_PAD_LAUNCH(true, 1); else MI355_PAD_LAUNCH(true, kMaxStages);
+#define MI355_PAD_FORMS(SPLIT_)                                     \
+  switch (form) {                                                   \
+    case 41: MI355_PAD_LAUNCH(SPLIT_, 1, 4); break;                 \
+    case 11: MI355_PAD_LAUNCH(SPLIT_, 1, 1); break;                 \
+    default: MI355_PAD_LAUNCH(SPLIT_, kMaxStages, 4); break;        \
   }
+  if (num_splits == 1) {
+    MI355_PAD_FORMS(false)
+  } else {
+    MI355_PAD_FORMS(true)
+  }
+#undef MI355_PAD_FORMS
 #undef MI355_PAD_LAUNCH
   int32_t rc = check_launch("mi355_paged_attn_decode");
   if (rc != MI355_OK || num_splits == 1) return rc;
