@@ -479,14 +479,16 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_decode_kernel(
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
 
-  // ---- merge the 4 waves through LDS: O as [wave][d][16 heads]
-  __shared__ float lds_o[NW][D * 16];
+  // ---- merge the waves through LDS: O as [wave][d][16 heads], a row padded to 17 words -- the readers below
+  // walk d at a fixed head, and at 16 words a row every lane of a wave would ask the same bank
+  constexpr int OW = 17;
+  __shared__ float lds_o[NW][D * OW];
   __shared__ float lds_m[NW][16];
   __shared__ float lds_l[NW][16];
 #pragma unroll
   for (int n = 0; n < NT; ++n)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) lds_o[wave][(16 * n + 4 * h + r) * 16 + c] = o[n][r];
+    for (int r = 0; r < 4; ++r) lds_o[wave][(16 * n + 4 * h + r) * OW + c] = o[n][r];
   if (h == 0) {
     lds_m[wave][c] = m;
     lds_l[wave][c] = l;
@@ -505,8 +507,8 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_decode_kernel(
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
         const float f = exp2f(lds_m[w][hh] - mg);
-        acc0 += f * lds_o[w][d * 16 + hh];
-        acc1 += f * lds_o[w][(d + 1) * 16 + hh];
+        acc0 += f * lds_o[w][d * OW + hh];
+        acc1 += f * lds_o[w][(d + 1) * OW + hh];
         lsum += f * lds_l[w][hh];
       }
     }
