@@ -676,7 +676,7 @@ int32_t mi355_linear_tiled_w8a8(void* y, int64_t y_stride, void* partial, const 
  *   connect  maps the peers' buffers; all_handles = world handles in rank order
  *   run      data: count 16-bit elements on this rank's GPU (count % 8 == 0, count * 2 <=
  *            max_bytes), summed over the ranks in place.  Every rank must issue the same calls
- *            with the same counts in the same order.  A peer that does not arrive within 2 s
+ *            with the same counts in the same order.  A peer that does not arrive within 10 s
  *            makes the kernel give up and leave data as it was:
  *   run_slabs  the same, but this rank's message is round(slabs[0] + ... + slabs[num_slabs - 1]):
  *            fp32 partial sums [num_slabs][count] of a K-split mi355_linear_tiled (epilogue 2),
@@ -691,6 +691,12 @@ int32_t mi355_linear_tiled_w8a8(void* y, int64_t y_stride, void* partial, const 
  *            followed by mi355_fused_add_rms_norm, one launch instead of two; the summed projection
  *            itself is not stored.  rows <= 256, hidden <= 8192.  On a timeout residual and out are
  *            left as they were
+ *   mi355_allreduce_twoshot_run_add_norm  the same call (same communicator, same arguments, bit-identical
+ *            results) in two hops for messages whose bytes set the time: the rows are dealt to the ranks in
+ *            contiguous slices, every rank sends each row only to the rank that owns it, the owner sums the
+ *            world rows in rank order and sends the finished 16-bit row to everybody -- 2 (world - 1) / world
+ *            message sizes over a rank's links instead of world - 1, one flag wait more.  Every rank must
+ *            choose the same form for the same call
  *   run_max_keys  the greedy pick of a step whose vocabulary is split over the ranks: keys[rows] are the
  *            (logit, index) keys of this rank's slice (mi355_argmax_shard_key); they are max-reduced
  *            over the ranks (signed 64-bit) and the winners' token ids written to out_ids (and to
@@ -714,6 +720,11 @@ int32_t mi355_allreduce_oneshot_run_slabs(void* comm, void* out, const float* sl
                                           int32_t num_slabs, int64_t count, int32_t dtype,
                                           void* stream);
 int32_t mi355_allreduce_oneshot_run_add_norm(void* comm, const void* data, const float* slabs,
+                                             int32_t num_slabs, void* residual,
+                                             int64_t residual_stride, const void* norm_weight,
+                                             void* out, int64_t out_stride, int32_t rows,
+                                             int32_t hidden, float eps, int32_t dtype, void* stream);
+int32_t mi355_allreduce_twoshot_run_add_norm(void* comm, const void* data, const float* slabs,
                                              int32_t num_slabs, void* residual,
                                              int64_t residual_stride, const void* norm_weight,
                                              void* out, int64_t out_stride, int32_t rows,

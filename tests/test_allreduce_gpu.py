@@ -119,13 +119,14 @@ def _worker(rank, world, conns, dtype, out_q):
                 ar.run(ref.view(-1))
             resid_ref, x_ref = resid0.clone(), T.empty(rows, hidden, dtype=tdt, device="cuda")
             ops.fused_add_rms_norm(ref, resid_ref, w, 1e-5, out=x_ref)
-            resid, x = resid0.clone(), T.full((rows, hidden), 7.0, dtype=tdt, device="cuda")
-            if n:
-                ar.run_add_norm(resid, w, 1e-5, x, slabs=sl, num_slabs=n)
-            else:
-                ar.run_add_norm(resid, w, 1e-5, x, data=mine)
-            T.cuda.synchronize()
-            assert T.equal(resid, resid_ref) and T.equal(x, x_ref), ("fused all-reduce + norm", rows, hidden, n)
+            for two in (False, True):                            # one hop; two hops (rows dealt to the ranks)
+                resid, x = resid0.clone(), T.full((rows, hidden), 7.0, dtype=tdt, device="cuda")
+                if n:
+                    ar.run_add_norm(resid, w, 1e-5, x, slabs=sl, num_slabs=n, two_shot=two)
+                else:
+                    ar.run_add_norm(resid, w, 1e-5, x, data=mine, two_shot=two)
+                T.cuda.synchronize()
+                assert T.equal(resid, resid_ref) and T.equal(x, x_ref), ("fused all-reduce + norm", rows, hidden, n, two)
             results.append(x.float().cpu().numpy().ravel())          # every rank must hold the same rows
         rows, hidden = 32, 4096
         mine = T.zeros(rows, hidden, dtype=tdt, device="cuda")
@@ -136,11 +137,20 @@ def _worker(rank, world, conns, dtype, out_q):
         g2 = T.cuda.CUDAGraph()
         with T.cuda.graph(g2):
             ar.run_add_norm(resid, w, 1e-5, x, data=mine)
+        resid2, x2 = T.zeros_like(resid), T.zeros_like(x)        # the two-hop form, captured too
+        ar.run_add_norm(resid2, w, 1e-5, x2, data=mine, two_shot=True)
+        T.cuda.synchronize()
+        g3 = T.cuda.CUDAGraph()
+        with T.cuda.graph(g3):
+            ar.run_add_norm(resid2, w, 1e-5, x2, data=mine, two_shot=True)
         for k in range(2):
             mine.copy_(T.from_numpy(_inputs(rank, 600 + k, rows * hidden, dtype)).to(tdt).view(rows, hidden))
             resid.copy_(T.from_numpy(_inputs(0, 700 + k, rows * hidden, dtype)).to(tdt).view(rows, hidden))
+            resid2.copy_(resid)
             g2.replay()
+            g3.replay()
             T.cuda.synchronize()
+            assert T.equal(resid, resid2) and T.equal(x, x2), ("two-hop form replayed from a graph", k)
             results.append(x.float().cpu().numpy().ravel())
             results.append(resid.float().cpu().numpy().ravel())
         # the greedy pick over a vocabulary split across the ranks: keys max-reduced and turned into ids in one launch

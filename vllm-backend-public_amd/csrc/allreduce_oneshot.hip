@@ -34,7 +34,10 @@ namespace mi355 {
 constexpr int kArMaxWorld = 8;   // (ar_load_all / ar_wait_all name eight registers)
 constexpr int kArMaxBlocks = 256;
 constexpr int kArThreads = 256;
-constexpr long long kSpinLimitTicks = 200000000LL;   // 2 s of the 100 MHz wall clock
+// 10 s of the 100 MHz wall clock: long against any skew between ranks that are alive (a rank that captures a
+// graph or times GEMM forms for a new batch size arrives seconds late; ranks sharing one card in a rehearsal
+// have been seen 2 s apart), short against a job that would otherwise hang for good
+constexpr long long kSpinLimitTicks = 1000000000LL;
 
 struct ArPeers {
   unsigned char* buf[kArMaxWorld];   // every rank's buffer as mapped into THIS process
@@ -306,6 +309,207 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(
   }
 }
 
+// The same all-reduce + residual add + norm in TWO hops, for messages whose bytes, not the latency of a hop, set
+// the time: a rank's links carry (world - 1) copies of the whole message in the one-shot form, 2 (world - 1) /
+// world copies here.  The rows are dealt to the ranks in contiguous slices; workgroup b of every rank handles
+// row b:
+//   1. a rank that does not own row b stores its row into ITS slot of the owner's buffer and raises flag
+//      [rank][b] there;
+//   2. the owner waits for those world - 1 flags, sums the world rows in RANK ORDER in fp32 (its own from
+//      registers), rounds once -- the value the one-shot form computes on every rank -- and stores the 16-bit
+//      row into ITS slot of every peer's buffer, then raises flag [owner][b] there;
+//   3. the others wait for that one flag and read the row from their own buffer; every rank then adds the
+//      residual and normalises, as in the one-shot form (bit-identical results: the same sum, the same order).
+// Slots and flags are the one-shot kernel's, used disjointly: row b of slot p at rank q holds p's partial row if
+// q owns b, p's finished row if p owns it, and nothing otherwise; rounds, parities and bounded waits as above (an
+// owner that gives up raises no flag, so its peers give up after their own wait).
+template <int NV>
+__device__ __forceinline__ void ar_wait_n(ar_u32x4 (&r)[NV]) {
+  static_assert(NV == 2 || NV == 4, "the waits below name two or four registers");
+  if constexpr (NV == 2)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1])::"memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3])::"memory");
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(kArThreads) void allreduce_twoshot_norm_kernel(
+    const uint16_t* __restrict__ data, int64_t count, ArPeers peers, int rank, int world, int64_t max_bytes,
+    unsigned* __restrict__ rounds, unsigned* __restrict__ error, const float* __restrict__ slabs, int num_slabs,
+    ArNorm nm) {
+  const int b = blockIdx.x, nb = gridDim.x, tid = threadIdx.x;
+  const unsigned round = __hip_atomic_load(rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  const int parity = round & 1;
+  const int per = nm.hidden >> 3;                      // 16-byte vectors of a row
+  const int64_t v0 = static_cast<int64_t>(b) * per;
+  const int rows_per = (nb + world - 1) / world;
+  const int owner = b / rows_per;                      // < world (b < nb <= rows_per * world); the same on every rank
+  const bool own_row = owner == rank;
+  const int64_t slot_bytes = max_bytes;
+  const int64_t flags_off = ar_flags_offset(world, max_bytes);
+  const int64_t parity_off = static_cast<int64_t>(parity) * world * slot_bytes;
+  const uint4* src = reinterpret_cast<const uint4*>(data);
+  unsigned char* local = peers.buf[rank];
+
+  // 1. this rank's row: into registers, and to the owner unless that is this rank.  A thread beyond the row
+  //    repeats the row's last vector (same value, same place).
+  uint4 own[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int64_t v = v0 + min(tid + i * kArThreads, per - 1);
+    if (slabs != nullptr) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < num_slabs; ++g) {
+        const float4* sp = reinterpret_cast<const float4*>(slabs + g * count + 8 * v);
+        const float4 a = sp[0], b4 = sp[1];
+        acc[0] += a.x, acc[1] += a.y, acc[2] += a.z, acc[3] += a.w;
+        acc[4] += b4.x, acc[5] += b4.y, acc[6] += b4.z, acc[7] += b4.w;
+      }
+      own[i] = pack8<T>(acc);
+    } else {
+      own[i] = src[v];
+    }
+    if (!own_row) ar_store_sys(peers.buf[owner] + parity_off + rank * slot_bytes + v * 16, own[i]);
+  }
+  uint4 nres[NV], nw[NV];
+  {
+    const uint4* rr = reinterpret_cast<const uint4*>(nm.residual + static_cast<int64_t>(b) * nm.res_stride);
+    const uint4* wv = reinterpret_cast<const uint4*>(nm.weight);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = min(tid + i * kArThreads, per - 1);
+      nres[i] = MI355_LD(uint4, nm.residual, rr + v);
+      nw[i] = MI355_LD(uint4, nm.weight, wv + v);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (!own_row && tid == 0) {
+    unsigned* flag = reinterpret_cast<unsigned*>(peers.buf[owner] + flags_off) + rank * kArMaxBlocks + b;
+    __hip_atomic_store(flag, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __shared__ int ok_s;
+  if (tid == 0) ok_s = 1;
+  __syncthreads();
+  // 2. / 3.  which lanes wait for whom: the owner's lanes p != rank for the rows of the peers, one lane of
+  //    everybody else for the owner's finished row
+  const bool waits = own_row ? (tid < world && tid != rank) : tid == 0;
+  if (waits) {
+    const int from = own_row ? tid : owner;
+    const unsigned* flag = reinterpret_cast<const unsigned*>(local + flags_off) + from * kArMaxBlocks + b;
+    const long long t0 = wall_clock64();
+    bool ok = true;
+    while (static_cast<int>(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - round) < 0) {
+      if (wall_clock64() - t0 > kSpinLimitTicks) {
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (!ok) {
+      ok_s = 0;
+      atomicExch(error, 1u + static_cast<unsigned>(from));
+    }
+  }
+  __syncthreads();
+  const bool ok_all = ok_s != 0;
+  uint4 red[NV];                                       // the finished 16-bit row, this thread's vectors
+#pragma unroll
+  for (int i = 0; i < NV; ++i) red[i] = make_uint4(0, 0, 0, 0);
+  if (own_row) {                                       // (workgroup-uniform)
+    if (ok_all) {
+      ar_u32x4 in[NV][kArMaxWorld];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int64_t v = v0 + min(tid + i * kArThreads, per - 1);
+        ar_load_all(in[i], local + parity_off, slot_bytes, v * 16, world, rank);
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int64_t v = v0 + min(tid + i * kArThreads, per - 1);
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        ar_wait_all(in[i]);
+#pragma unroll
+        for (int p = 0; p < kArMaxWorld; ++p) {
+          if (p < world) {
+            float g[8];
+            unpack8<T>(p == rank ? own[i] : make_uint4(in[i][p].x, in[i][p].y, in[i][p].z, in[i][p].w), g);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] += g[q];
+          }
+        }
+        red[i] = pack8<T>(acc);
+        for (int p = 0; p < world; ++p)
+          if (p != rank) ar_store_sys(peers.buf[p] + parity_off + rank * slot_bytes + v * 16, red[i]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (ok_all && tid < world && tid != rank) {
+      unsigned* flag = reinterpret_cast<unsigned*>(peers.buf[tid] + flags_off) + rank * kArMaxBlocks + b;
+      __hip_atomic_store(flag, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  } else if (ok_all) {
+    ar_u32x4 in[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      in[i] = ar_load_sys(local + parity_off + owner * slot_bytes + (v0 + min(tid + i * kArThreads, per - 1)) * 16);
+    ar_wait_n<NV>(in);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[i] = make_uint4(in[i].x, in[i].y, in[i].z, in[i].w);
+  }
+  // residual add + norm of the finished row: the arithmetic, thread-to-vector map and summation order of the
+  // one-shot form (and of rms_norm_slabs_kernel)
+  __shared__ float part[kArThreads / 64];
+  float f[NV][8];
+  float ss = 0.f;
+  if (ok_all) {
+    uint4* rr = reinterpret_cast<uint4*>(nm.residual + static_cast<int64_t>(b) * nm.res_stride);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + i * kArThreads;
+      float r[8];
+      unpack8<T>(red[i], f[i]);
+      unpack8<T>(nres[i], r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[i][j] = round_f<T>(f[i][j] + r[j]);
+      if (v < per) {
+        MI355_ST(uint4, nm.residual, rr + v, pack8<T>(f[i]));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += f[i][j] * f[i][j];
+      }
+    }
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) part[tid >> 6] = ss;
+  __syncthreads();
+  if (ok_all) {
+    float total = 0.f;
+#pragma unroll
+    for (int i = 0; i < kArThreads / 64; ++i) total += part[i];
+    const float inv = 1.0f / sqrtf(total / static_cast<float>(nm.hidden) + nm.eps);
+    uint4* orow = reinterpret_cast<uint4*>(nm.out + static_cast<int64_t>(b) * nm.out_stride);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + i * kArThreads;
+      float w[8], y[8];
+      unpack8<T>(nw[i], w);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = round_f<T>(f[i][j] * inv) * w[j];
+      if (v < per) MI355_ST(uint4, nm.out, orow + v, pack8<T>(y));
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (__hip_atomic_fetch_add(rounds + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(nb - 1)) {
+      __hip_atomic_store(rounds + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rounds, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // Max-reduce of one 64-bit key per row (the greedy pick of a vocabulary-sharded step: every rank holds the
 // (logit, index) key of its slice's best token, mi355_argmax_shard_key) and the token ids of the winners, in
 // ONE workgroup: thread t delivers key t to the peers' slots, the flags of chunk 0 say when theirs are here,
@@ -447,7 +651,7 @@ extern "C" int32_t mi355_allreduce_oneshot_connect(void* comm, const void* all_h
 
 static int32_t allreduce_oneshot_launch(const char* name, void* comm, void* data, const float* slabs, int32_t num_slabs,
                                         int64_t count, int32_t dtype, void* stream, const mi355::ArNorm* norm = nullptr,
-                                        int32_t rows = 0) {
+                                        int32_t rows = 0, bool two_shot = false) {
   using namespace mi355;
   MI355_REQUIRE(comm && (data || (norm && slabs)), MI355_ERR_INVALID, "%s: null pointer", name);
   ArComm* c = static_cast<ArComm*>(comm);
@@ -470,7 +674,18 @@ static int32_t allreduce_oneshot_launch(const char* name, void* comm, void* data
 #define MI355_AR_LAUNCH(T_, NV_, NB_, NM_)                                                                               \
   hipLaunchKernelGGL((allreduce_oneshot_kernel<T_, NV_>), dim3(NB_), dim3(kArThreads), 0, s, static_cast<uint16_t*>(data), \
                      count, peers, c->rank, c->world, c->max_bytes, c->rounds, c->error, slabs, num_slabs, NM_)
-  if (norm != nullptr) {             // one workgroup per row (the same count on every rank: it is the row count)
+#define MI355_AR2_LAUNCH(T_, NV_)                                                                                          \
+  hipLaunchKernelGGL((allreduce_twoshot_norm_kernel<T_, NV_>), dim3(rows), dim3(kArThreads), 0, s,                         \
+                     static_cast<const uint16_t*>(data), count, peers, c->rank, c->world, c->max_bytes, c->rounds, c->error, \
+                     slabs, num_slabs, *norm)
+  if (norm != nullptr && two_shot) {
+    const bool wide = (norm->hidden >> 3) > 2 * kArThreads;
+    if (dtype == MI355_BF16) {
+      if (wide) MI355_AR2_LAUNCH(BF16, 4); else MI355_AR2_LAUNCH(BF16, 2);
+    } else {
+      if (wide) MI355_AR2_LAUNCH(F16, 4); else MI355_AR2_LAUNCH(F16, 2);
+    }
+  } else if (norm != nullptr) {      // one workgroup per row (the same count on every rank: it is the row count)
     const bool wide = (norm->hidden >> 3) > 2 * kArThreads;
     if (dtype == MI355_BF16) {
       if (wide) MI355_AR_LAUNCH(BF16, 4, rows, *norm); else MI355_AR_LAUNCH(BF16, 2, rows, *norm);
@@ -483,6 +698,7 @@ static int32_t allreduce_oneshot_launch(const char* name, void* comm, void* data
     MI355_AR_LAUNCH(F16, 0, nb, ArNorm{});
   }
 #undef MI355_AR_LAUNCH
+#undef MI355_AR2_LAUNCH
   return check_launch(name);
 }
 
@@ -498,12 +714,11 @@ extern "C" int32_t mi355_allreduce_oneshot_run_slabs(void* comm, void* out, cons
   return allreduce_oneshot_launch(name, comm, out, slabs, num_slabs, count, dtype, stream);
 }
 
-extern "C" int32_t mi355_allreduce_oneshot_run_add_norm(void* comm, const void* data, const float* slabs, int32_t num_slabs,
+static int32_t allreduce_add_norm_entry(const char* name, bool two_shot, void* comm, const void* data, const float* slabs, int32_t num_slabs,
                                                         void* residual, int64_t residual_stride, const void* norm_weight,
                                                         void* out, int64_t out_stride, int32_t rows, int32_t hidden,
                                                         float eps, int32_t dtype, void* stream) {
   using namespace mi355;
-  const char* name = "mi355_allreduce_oneshot_run_add_norm";
   MI355_REQUIRE(residual && norm_weight && out && (data || slabs), MI355_ERR_INVALID, "%s: null pointer", name);
   MI355_REQUIRE(rows >= 0 && rows <= kArMaxBlocks, MI355_ERR_UNSUPPORTED, "%s: rows %d outside [0, %d]", name, rows,
                 kArMaxBlocks);
@@ -517,7 +732,23 @@ extern "C" int32_t mi355_allreduce_oneshot_run_add_norm(void* comm, const void* 
   const ArNorm nm{static_cast<uint16_t*>(residual), static_cast<const uint16_t*>(norm_weight), static_cast<uint16_t*>(out),
                   residual_stride, out_stride, hidden, eps};
   return allreduce_oneshot_launch(name, comm, const_cast<void*>(data), slabs, slabs ? num_slabs : 0,
-                                  static_cast<int64_t>(rows) * hidden, dtype, stream, &nm, rows);
+                                  static_cast<int64_t>(rows) * hidden, dtype, stream, &nm, rows, two_shot);
+}
+
+extern "C" int32_t mi355_allreduce_oneshot_run_add_norm(void* comm, const void* data, const float* slabs, int32_t num_slabs,
+                                                        void* residual, int64_t residual_stride, const void* norm_weight,
+                                                        void* out, int64_t out_stride, int32_t rows, int32_t hidden,
+                                                        float eps, int32_t dtype, void* stream) {
+  return allreduce_add_norm_entry("mi355_allreduce_oneshot_run_add_norm", false, comm, data, slabs, num_slabs, residual,
+                                  residual_stride, norm_weight, out, out_stride, rows, hidden, eps, dtype, stream);
+}
+
+extern "C" int32_t mi355_allreduce_twoshot_run_add_norm(void* comm, const void* data, const float* slabs, int32_t num_slabs,
+                                                        void* residual, int64_t residual_stride, const void* norm_weight,
+                                                        void* out, int64_t out_stride, int32_t rows, int32_t hidden,
+                                                        float eps, int32_t dtype, void* stream) {
+  return allreduce_add_norm_entry("mi355_allreduce_twoshot_run_add_norm", true, comm, data, slabs, num_slabs, residual,
+                                  residual_stride, norm_weight, out, out_stride, rows, hidden, eps, dtype, stream);
 }
 
 extern "C" int32_t mi355_allreduce_oneshot_run_max_keys(void* comm, const int64_t* keys, int64_t* out_ids,
@@ -558,7 +789,7 @@ extern "C" int32_t mi355_allreduce_oneshot_status(void* comm) {
   unsigned err = 0;
   const hipError_t e = hipMemcpy(&err, c->error, sizeof(err), hipMemcpyDeviceToHost);   // waits for the work queued before it
   MI355_REQUIRE(e == hipSuccess, MI355_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
-  MI355_REQUIRE(err == 0, MI355_ERR_LAUNCH, "%s: rank %d waited 2 s for rank %u, which never delivered its chunk", name, c->rank,
+  MI355_REQUIRE(err == 0, MI355_ERR_LAUNCH, "%s: rank %d waited 10 s for rank %u, which never delivered its chunk", name, c->rank,
                 err - 1);
   return MI355_OK;
 }

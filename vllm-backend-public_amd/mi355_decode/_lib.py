@@ -90,6 +90,7 @@ def _load() -> ctypes.CDLL:
         "mi355_allreduce_oneshot_run": (I32, [P, P, I64, I32, P]),
         "mi355_allreduce_oneshot_run_slabs": (I32, [P, P, P, I32, I64, I32, P]),
         "mi355_allreduce_oneshot_run_add_norm": (I32, [P, P, P, I32, P, I64, P, P, I64, I32, I32, F, I32, P]),
+        "mi355_allreduce_twoshot_run_add_norm": (I32, [P, P, P, I32, P, I64, P, P, I64, I32, I32, F, I32, P]),
         "mi355_allreduce_oneshot_run_max_keys": (I32, [P, P, P, P, I32, P]),
         "mi355_allreduce_oneshot_status": (I32, [P]),
         "mi355_allreduce_oneshot_status_async": (I32, [P, P, P]),
@@ -122,7 +123,7 @@ EXPORTS = ("mi355_abi_version", "mi355_last_error", "mi355_target_arch",
            "mi355_quant_rows_fp8", "mi355_linear_tiled_w8a8",
            "mi355_token_logprobs", "mi355_topk_logits",
            "mi355_allreduce_oneshot_handle_bytes", "mi355_allreduce_oneshot_init", "mi355_allreduce_oneshot_connect",
-           "mi355_allreduce_oneshot_run", "mi355_allreduce_oneshot_run_slabs", "mi355_allreduce_oneshot_run_add_norm", "mi355_allreduce_oneshot_run_max_keys",
+           "mi355_allreduce_oneshot_run", "mi355_allreduce_oneshot_run_slabs", "mi355_allreduce_oneshot_run_add_norm", "mi355_allreduce_twoshot_run_add_norm", "mi355_allreduce_oneshot_run_max_keys",
            "mi355_allreduce_oneshot_status",
            "mi355_allreduce_oneshot_status_async", "mi355_allreduce_oneshot_destroy")
 

@@ -18,6 +18,7 @@ rank could not map a buffer or saw a wrong sum."""
 from __future__ import annotations
 
 import ctypes
+import os
 import logging
 
 import torch
@@ -88,12 +89,29 @@ class OneShotAllReduce:
         return (dtype in (torch.bfloat16, torch.float16) and 0 < rows <= self.MAX_NORM_ROWS and hidden % 8 == 0
                 and hidden <= self.MAX_NORM_HIDDEN and rows * hidden * 2 <= self.max_bytes)
 
+    TWO_SHOT_MIN_BYTES = 512 << 10
+
+    def two_shot(self, rows: int, hidden: int) -> bool:
+        """Which form run_add_norm takes for a [rows, hidden] message -- a function of the communicator and the
+        shape only, so every rank answers alike.  The two-hop form moves 2 (world - 1) / world message sizes over
+        a rank's links instead of world - 1 and waits for one flag more: from four ranks and 512 KiB on the bytes
+        outweigh the hop (arithmetic on the links' rate; no multi-GPU box has timed either form).
+        MI355_ALLREDUCE_TWO_SHOT=0 / 1 forces a form."""
+        forced = os.environ.get("MI355_ALLREDUCE_TWO_SHOT", "")
+        if forced in ("0", "1"):
+            return forced == "1"
+        return self.world >= 4 and rows >= self.world and rows * hidden * 2 >= self.TWO_SHOT_MIN_BYTES
+
     def run_add_norm(self, residual: torch.Tensor, weight: torch.Tensor, eps: float, out: torch.Tensor,
-                     data: torch.Tensor | None = None, slabs: torch.Tensor | None = None, num_slabs: int = 0) -> torch.Tensor:
+                     data: torch.Tensor | None = None, slabs: torch.Tensor | None = None, num_slabs: int = 0,
+                     two_shot: bool | None = None) -> torch.Tensor:
         """The all-reduce of a projection's [rows, hidden] result and the residual add + RMSNorm behind it in one
         launch: residual += sum over the ranks (of `data`, or of the rounded slab sum), out = norm(residual) * weight;
-        bit-identical to run / run_slabs followed by ops.fused_add_rms_norm.  The reduced projection is not stored."""
+        bit-identical to run / run_slabs followed by ops.fused_add_rms_norm.  The reduced projection is not stored.
+        `two_shot`: the two-hop form (same results); None: self.two_shot(rows, hidden).  Every rank must pass the same."""
         rows, hidden = residual.shape
+        if two_shot is None:
+            two_shot = self.two_shot(rows, hidden)
         if not self.fits_add_norm(rows, hidden, residual.dtype):
             raise ValueError(f"one-shot all-reduce + norm takes up to {self.MAX_NORM_ROWS} rows of up to "
                              f"{self.MAX_NORM_HIDDEN} 16-bit elements within {self.max_bytes} bytes")
@@ -110,7 +128,8 @@ class OneShotAllReduce:
         if slabs is not None and (slabs.dtype != torch.float32 or not slabs.is_cuda or not slabs.is_contiguous()
                                   or num_slabs < 1 or slabs.numel() < num_slabs * rows * hidden):
             raise ValueError("slabs must be contiguous float32 holding [num_slabs, rows * hidden]")
-        check(lib.mi355_allreduce_oneshot_run_add_norm(
+        fn = lib.mi355_allreduce_twoshot_run_add_norm if two_shot else lib.mi355_allreduce_oneshot_run_add_norm
+        check(fn(
             self._comm, data.data_ptr() if data is not None else 0, slabs.data_ptr() if slabs is not None else 0,
             num_slabs, residual.data_ptr(), residual.stride(0), weight.data_ptr(), out.data_ptr(), out.stride(0),
             rows, hidden, float(eps), _DT[residual.dtype], _stream()))
@@ -143,7 +162,7 @@ class OneShotAllReduce:
         """After the stream work behind queue_status(slot) has completed: raises if a peer failed to arrive."""
         word = int(self.host_word[slot])
         if word != 0:
-            raise Mi355Error(f"one-shot all-reduce: rank {self.rank} waited 2 s for rank {word - 1}, which never delivered "
+            raise Mi355Error(f"one-shot all-reduce: rank {self.rank} waited 10 s for rank {word - 1}, which never delivered "
                              "its chunk; this rank's activations were not reduced -- stopping instead of serving them")
 
     def self_test(self, device) -> bool:
@@ -173,10 +192,14 @@ class OneShotAllReduce:
                     data = torch.full((rows, hidden), float(self.rank + 1), dtype=torch.bfloat16, device=device)
                     resid = torch.zeros(rows, hidden, dtype=torch.bfloat16, device=device)
                     x = torch.zeros(rows, hidden, dtype=torch.bfloat16, device=device)
-                    self.run_add_norm(resid, torch.ones(hidden, dtype=torch.bfloat16, device=device), 1e-5, x, data=data)
                     c = self.world * (self.world + 1) / 2.0
                     want_x = torch.tensor(c, dtype=torch.float32).mul(torch.rsqrt(torch.tensor(c * c + 1e-5))).to(torch.bfloat16)
-                    ok &= bool((resid == c).all().item()) and bool((x.float() - want_x.float()).abs().max().item() <= 2 ** -7)
+                    for two in (False, True):                    # one hop, then the two-hop form
+                        resid.zero_()
+                        x.zero_()
+                        self.run_add_norm(resid, torch.ones(hidden, dtype=torch.bfloat16, device=device), 1e-5, x, data=data,
+                                          two_shot=two)
+                        ok &= bool((resid == c).all().item()) and bool((x.float() - want_x.float()).abs().max().item() <= 2 ** -7)
                     keys = torch.tensor([((self.rank + 1) << 32) | (0xFFFFFFFF - (100 * self.rank + i)) for i in range(rows)],
                                         dtype=torch.int64, device=device)
                     ids = torch.full((rows,), -1, dtype=torch.int64, device=device)
