@@ -38,12 +38,13 @@ def _worker(rank, world, port, name, dtype, shard_mlp, q, oneshot=False):
                 sys.path.insert(0, p)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                           LOCAL_RANK="0", MI355_DIST_BACKEND="gloo", MI355_TP_MLP="1" if shard_mlp else "0",
-                          MI355_TP_VOCAB="1" if shard_mlp else "0", MI355_ONESHOT_ALLREDUCE="1" if oneshot else "0")
+                          MI355_TP_VOCAB="1" if shard_mlp else "0", MI355_ONESHOT_ALLREDUCE="1" if oneshot else "0",
+                          MI355_ALLREDUCE_TWO_SHOT="1" if oneshot == "graphs-two-hop" else "0")
         import torch
         import torch.distributed as dist
         from test_model_gpu import build, engine_generate
         from oracle.tiny_models import make_prompts
-        graphs = oneshot == "graphs"     # with every decode collective on the one-shot kernel the step is captured, gloo or not
+        graphs = oneshot in ("graphs", "graphs-two-hop")     # with every decode collective on the one-shot kernel the step is captured, gloo or not
         eng, cfg, w = build(name, dtype, tensor_parallel_size=world, enforce_eager=not graphs)
         r = eng.runner
         assert r.use_graphs == graphs
@@ -113,9 +114,10 @@ def _worker(rank, world, port, name, dtype, shard_mlp, q, oneshot=False):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shard_mlp,oneshot", [(True, False), (False, False), (True, True), (True, "graphs")],
+@pytest.mark.parametrize("shard_mlp,oneshot", [(True, False), (False, False), (True, True), (True, "graphs"),
+                                               (True, "graphs-two-hop")],
                          ids=["mlp_sharded", "mlp_replicated", "mlp_sharded_oneshot_allreduce",
-                              "mlp_sharded_oneshot_allreduce_in_hip_graphs"])
+                              "mlp_sharded_oneshot_allreduce_in_hip_graphs", "mlp_sharded_two_hop_allreduce_in_hip_graphs"])
 @pytest.mark.parametrize("name,dtype", [("llama_d128", "bfloat16"), ("qwen2_d128", "float16")])
 def test_two_ranks_generate_like_the_unsharded_oracle(name, dtype, shard_mlp, oneshot):
     import torch.multiprocessing as mp
