@@ -769,7 +769,9 @@ def main():
                           "gemm_tune_failures": r_.tune_failures,
                           "allreduce": ("none (1 GPU)" if tp == 1 else
                                         "one-shot kernel over IPC-mapped buffers (self-test passed on every rank); "
-                                        "larger messages on " + dist.get_backend() if r_.oneshot is not None else
+                                        + ("the decode step's all-reduce + add + norm in two hops (rows dealt to the ranks); "
+                                           if r_.oneshot is not None and r_.oneshot.two_shot(batch, cfg.hidden_size) else "")
+                                        + "larger messages on " + dist.get_backend() if r_.oneshot is not None else
                                         ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal)")
                                         + (" -- the one-shot kernel's set-up or self-test failed, fell back"
                                            if r_.oneshot_fallbacks else "")),
